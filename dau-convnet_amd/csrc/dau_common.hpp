@@ -1,0 +1,51 @@
+// Shared declarations of the HIP implementation behind include/dau_conv.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include "dau_conv.h"
+
+namespace dau {
+
+constexpr int kMaxBlurSupport = 17;                       // convolve.cu:40 caps the prefilter at 17x17
+constexpr int kFilterPlane = kMaxBlurSupport * kMaxBlurSupport;
+constexpr int kNumK = 4;                                  // gradient kinds {w, mu1, mu2, sigma}
+
+// Device-side status block at the head of every workspace (see dau_conv_check_status).
+struct Status {
+    unsigned int max_abs_mu_bits;  // float bits of max(|mu1|,|mu2|); valid because |x| bits order like uints
+    unsigned int nan_seen;
+    unsigned int pad[2];
+};
+
+// One prepared unit for the gather kernels: integer displacement and the four
+// bilinear weights already multiplied by w (dau_conv_forward_core.hpp:2155-2213).
+struct UnitRef {
+    int ox, oy;
+    float w00, w01, w10, w11;
+};
+
+struct Shape {
+    int N, S, F, G, H, W;
+};
+
+// ---- launchers implemented in the kernel TUs --------------------------------------
+// k_filters.hip
+void launch_synth_filters(hipStream_t st, const float* sigma_dev, int k, int flags, float* filters6);
+// k_units.hip
+void launch_prepare_units(hipStream_t st, const float* w, const float* mu1, const float* mu2, Shape sh,
+                          int ignore, int flags, int bucket, bool transposed_negated, UnitRef* table,
+                          Status* status);
+void launch_unit_table_export(hipStream_t st, const float* mu1, const float* mu2, long units, int flags,
+                              int32_t* offsets, float* factors);
+void launch_finalize_grads(hipStream_t st, const float* r4, const float* w, Shape sh, int ignore, float lr,
+                           int need_mask, bool single_dim, float* dw, float* dmu1, float* dmu2, float* dsigma);
+// k_direct.hip  (DAU_ALGO_DIRECT: plain kernels, any shape)
+void launch_blur_direct(hipStream_t st, const float* x, long planes, int H, int W, const float* filters,
+                        int nfilt, int k, float* out);
+void launch_gather_sum_direct(hipStream_t st, const float* xb, const UnitRef* table, int N, int Sin, int Fout,
+                              int G, int H, int W, float* y);
+void launch_gather_dot_direct(hipStream_t st, const float* xk4, const float* err, const UnitRef* table, Shape sh,
+                              int drop_col, int drop_row, float* r4);
+
+}  // namespace dau

@@ -1,0 +1,334 @@
+// C ABI (include/dau_conv.h) and pass orchestration.
+//
+// Sequencing follows what the reference does between its op boundary and its kernels
+// (plugins/tensorflow/src/dau_conv_op.cpp:150-324, dau_conv_grad_op.cpp:115-318,
+//  src/dau_conv/base_dau_conv_layer.cu:15-127 Forward_gpu, :130-363 Backward_gpu), minus
+// the per-call handle creation, side streams, host syncs and workspace re-allocation.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "dau_common.hpp"
+#include "dau_tiled.hpp"
+
+using namespace dau;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define DAU_HIP(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return fail(DAU_INTERNAL, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// bump allocator over the caller's workspace
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+    template <typename T>
+    T* take(size_t count) {
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off = align_up(off + count * sizeof(T));
+        return p;
+    }
+};
+
+// unit_testing edge rule of the numpy oracle (dau_conv_test.py:110-136)
+int edge_disabled(int size) {
+    if (size >= 64) return size % 64 == 0;
+    if (size >= 32) return size % 32 == 0;
+    if (size >= 16) return size % 16 == 0;
+    if (size >= 8) return size % 8 == 0;
+    return 0;
+}
+
+}  // namespace
+
+struct dau_conv_plan {
+    dau_conv_desc d;
+    Shape sh;
+    int bucket;        // offset bucket R
+    int blur_k;        // prefilter support
+    int drop_col, drop_row;
+    int algo_fwd, algo_bwd;
+    TiledConfig tiled_fwd;   // gather-sum y  : S -> F
+    TiledConfig tiled_dx;    // gather-sum dx : F -> S
+    TiledDotConfig tiled_dot;
+    long units() const { return (long)sh.S * sh.G * sh.F; }
+};
+
+namespace {
+
+struct FwdWs {
+    Status* status;
+    float* filters;
+    UnitRef* table;
+    float* xb;          // direct: blurred input, NCHW
+    void* tiled;        // tiled: staged planes + packed units
+    size_t bytes;
+};
+
+FwdWs carve_forward(const dau_conv_plan* p, void* ws) {
+    Carver c(ws);
+    FwdWs w{};
+    w.status = c.take<Status>(1);
+    w.filters = c.take<float>(6 * kFilterPlane);
+    w.table = c.take<UnitRef>(p->units());
+    if (p->algo_fwd == DAU_ALGO_TILED) {
+        w.tiled = c.take<char>(tiled_gather_workspace_bytes(p->tiled_fwd));
+    } else {
+        w.xb = c.take<float>((size_t)p->sh.N * p->sh.S * p->sh.H * p->sh.W);
+    }
+    w.bytes = c.off;
+    return w;
+}
+
+struct BwdWs {
+    Status* status;
+    float* filters;
+    UnitRef* table_bare;   // [S][G][F], w = 1  (parameter gradients)
+    UnitRef* table_t;      // [F][G][S], negated offsets, times w  (input gradient)
+    float* r4;             // [4][S][G][F]
+    float* xk4;            // direct: [N*S][4][H][W]
+    float* eb;             // direct: blurred error, NCHW
+    void* tiled_dx;
+    void* tiled_dot;
+    size_t bytes;
+};
+
+BwdWs carve_backward(const dau_conv_plan* p, void* ws) {
+    Carver c(ws);
+    BwdWs w{};
+    const Shape& s = p->sh;
+    w.status = c.take<Status>(1);
+    w.filters = c.take<float>(6 * kFilterPlane);
+    w.table_bare = c.take<UnitRef>(p->units());
+    w.table_t = c.take<UnitRef>(p->units());
+    w.r4 = c.take<float>(kNumK * p->units());
+    if (p->algo_bwd == DAU_ALGO_TILED) {
+        w.tiled_dot = c.take<char>(tiled_dot_workspace_bytes(p->tiled_dot));
+    } else {
+        w.xk4 = c.take<float>((size_t)kNumK * s.N * s.S * s.H * s.W);
+    }
+    if (p->algo_fwd == DAU_ALGO_TILED) {
+        w.tiled_dx = c.take<char>(tiled_gather_workspace_bytes(p->tiled_dx));
+    } else {
+        w.eb = c.take<float>((size_t)s.N * s.F * s.H * s.W);
+    }
+    w.bytes = c.off;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dau_conv_abi_version(void) { return DAU_CONV_ABI_VERSION; }
+
+const char* dau_conv_last_error(void) { return g_last_error.c_str(); }
+
+int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
+    if (!desc || !plan_out) return fail(DAU_INVALID_ARGUMENT, "null argument");
+    if (desc->struct_size != (int32_t)sizeof(dau_conv_desc))
+        return fail(DAU_INVALID_ARGUMENT, "dau_conv_desc.struct_size %d != %zu", desc->struct_size, sizeof(dau_conv_desc));
+    if (desc->batch < 1 || desc->in_channels < 1 || desc->out_channels < 1 || desc->units_per_channel < 1 ||
+        desc->height < 1 || desc->width < 1)
+        return fail(DAU_INVALID_ARGUMENT, "all of N,S,F,G,H,W must be >= 1");
+    if (desc->number_units_ignore < 0 || desc->number_units_ignore >= desc->units_per_channel)
+        return fail(DAU_INVALID_ARGUMENT, "number_units_ignore must be in [0, G)");
+    if (desc->max_kernel_size < 3 || desc->max_kernel_size % 2 == 0)
+        return fail(DAU_INVALID_ARGUMENT, "kernel_size must be odd and >= 3");
+    // offset bucket from the largest displacement the attrs allow (dau_conv_op.cpp:236-253)
+    const int half = desc->max_kernel_size / 2;
+    int bucket;
+    if (half <= 4) bucket = 4;
+    else if (half <= 8) bucket = 8;
+    else if (half <= 16) bucket = 16;
+    else if (half <= 32) bucket = 32;
+    else
+        return fail(DAU_INVALID_ARGUMENT,
+                    "DAUConv: offsets larger than the 32 px the kernels stage (set max_kernel_size <= 65)");
+    if (!(desc->sigma_hint > 0.0f))  // DAU_CHECK(sigma > 0) base_dau_conv_layer.cpp:143
+        return fail(DAU_FAILED_PRECONDITION, "Must use sigma > 0 - initialize it with appropriate value");
+    const int blur_k = 2 * (int)std::ceil(5.0f * desc->sigma_hint) + 1;  // base_dau_conv_layer.cpp:146
+    if (blur_k > kMaxBlurSupport)
+        return fail(DAU_INVALID_ARGUMENT, "sigma %.3f needs a %dx%d prefilter; at most %dx%d is supported", desc->sigma_hint,
+                    blur_k, blur_k, kMaxBlurSupport, kMaxBlurSupport);
+    if (desc->algo < DAU_ALGO_AUTO || desc->algo > DAU_ALGO_TILED) return fail(DAU_INVALID_ARGUMENT, "unknown algo");
+
+    dau_conv_plan* p = new (std::nothrow) dau_conv_plan();
+    if (!p) return fail(DAU_INTERNAL, "out of host memory");
+    p->d = *desc;
+    p->sh = Shape{desc->batch, desc->in_channels, desc->out_channels, desc->units_per_channel, desc->height, desc->width};
+    p->bucket = bucket;
+    p->blur_k = blur_k;
+    const bool ut = desc->flags & DAU_FLAG_UNIT_TESTING;
+    p->drop_col = ut ? edge_disabled(desc->width) : 0;
+    p->drop_row = ut ? edge_disabled(desc->height) : 0;
+
+    const Shape& s = p->sh;
+    const bool fwd_ok = tiled_gather_configure(s.N, s.S, s.F, s.G, s.H, s.W, bucket, blur_k, &p->tiled_fwd) &&
+                        tiled_gather_configure(s.N, s.F, s.S, s.G, s.H, s.W, bucket, blur_k, &p->tiled_dx);
+    const bool dot_ok = tiled_dot_configure(s, bucket, blur_k, &p->tiled_dot);
+    if (desc->algo == DAU_ALGO_TILED && !(fwd_ok && dot_ok)) {
+        delete p;
+        return fail(DAU_INVALID_ARGUMENT, "DAU_ALGO_TILED does not support this shape");
+    }
+    p->algo_fwd = (desc->algo != DAU_ALGO_DIRECT && fwd_ok) ? DAU_ALGO_TILED : DAU_ALGO_DIRECT;
+    p->algo_bwd = (desc->algo != DAU_ALGO_DIRECT && dot_ok) ? DAU_ALGO_TILED : DAU_ALGO_DIRECT;
+    *plan_out = p;
+    return DAU_OK;
+}
+
+int dau_conv_plan_destroy(dau_conv_plan* plan) {
+    delete plan;
+    return DAU_OK;
+}
+
+int dau_conv_plan_get_info(const dau_conv_plan* plan, dau_conv_plan_info* info) {
+    if (!plan || !info) return fail(DAU_INVALID_ARGUMENT, "null argument");
+    info->offset_bucket = plan->bucket;
+    info->blur_support = plan->blur_k;
+    info->algo_forward = plan->algo_fwd;
+    info->algo_backward = plan->algo_bwd;
+    info->drop_last_col = plan->drop_col;
+    info->drop_last_row = plan->drop_row;
+    return DAU_OK;
+}
+
+int dau_conv_workspace_bytes(const dau_conv_plan* plan, int pass, size_t* bytes_out) {
+    if (!plan || !bytes_out) return fail(DAU_INVALID_ARGUMENT, "null argument");
+    if (pass == DAU_PASS_FORWARD) *bytes_out = carve_forward(plan, nullptr).bytes;
+    else if (pass == DAU_PASS_BACKWARD) *bytes_out = carve_backward(plan, nullptr).bytes;
+    else return fail(DAU_INVALID_ARGUMENT, "pass must be DAU_PASS_FORWARD or DAU_PASS_BACKWARD");
+    return DAU_OK;
+}
+
+int dau_conv_forward(const dau_conv_plan* p, void* stream, const float* x, const float* w, const float* mu1,
+                     const float* mu2, const float* sigma, float* y, void* workspace, size_t workspace_bytes) {
+    if (!p || !x || !w || !mu1 || !mu2 || !sigma || !y || !workspace) return fail(DAU_INVALID_ARGUMENT, "null argument");
+    FwdWs ws = carve_forward(p, workspace);
+    if (workspace_bytes < ws.bytes)
+        return fail(DAU_INVALID_ARGUMENT, "workspace too small: %zu < %zu", workspace_bytes, ws.bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Shape& s = p->sh;
+    DAU_HIP(hipMemsetAsync(ws.status, 0, sizeof(Status), st));
+    launch_synth_filters(st, sigma, p->blur_k, p->d.flags, ws.filters);
+    launch_prepare_units(st, w, mu1, mu2, s, p->d.number_units_ignore, p->d.flags, p->bucket, false, ws.table, ws.status);
+    if (p->algo_fwd == DAU_ALGO_TILED) {
+        tiled_gather_run(st, p->tiled_fwd, x, ws.filters + 0 * kFilterPlane, ws.table, y, ws.tiled);
+    } else {
+        launch_blur_direct(st, x, (long)s.N * s.S, s.H, s.W, ws.filters + 0 * kFilterPlane, 1, p->blur_k, ws.xb);
+        launch_gather_sum_direct(st, ws.xb, ws.table, s.N, s.S, s.F, s.G, s.H, s.W, y);
+    }
+    DAU_HIP(hipPeekAtLastError());
+    return DAU_OK;
+}
+
+int dau_conv_backward(const dau_conv_plan* p, void* stream, const float* x, const float* dy, const float* w,
+                      const float* mu1, const float* mu2, const float* sigma, float* dx, float* dw, float* dmu1,
+                      float* dmu2, float* dsigma, void* workspace, size_t workspace_bytes, int need_mask) {
+    if (!p || !x || !dy || !w || !mu1 || !mu2 || !sigma || !workspace) return fail(DAU_INVALID_ARGUMENT, "null argument");
+    if (((need_mask & DAU_NEED_DX) && !dx) || ((need_mask & DAU_NEED_DW) && !dw) ||
+        ((need_mask & DAU_NEED_DMU1) && !dmu1) || ((need_mask & DAU_NEED_DMU2) && !dmu2) ||
+        ((need_mask & DAU_NEED_DSIGMA) && !dsigma))
+        return fail(DAU_INVALID_ARGUMENT, "need_mask asks for a gradient whose output pointer is null");
+    BwdWs ws = carve_backward(p, workspace);
+    if (workspace_bytes < ws.bytes)
+        return fail(DAU_INVALID_ARGUMENT, "workspace too small: %zu < %zu", workspace_bytes, ws.bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Shape& s = p->sh;
+    const int flags = p->d.flags;
+    DAU_HIP(hipMemsetAsync(ws.status, 0, sizeof(Status), st));
+    launch_synth_filters(st, sigma, p->blur_k, flags, ws.filters);
+
+    const int param_mask = DAU_NEED_DW | DAU_NEED_DMU1 | DAU_NEED_DMU2 | DAU_NEED_DSIGMA;
+    if (need_mask & param_mask) {
+        // parameter gradients: r_k = offset_and_dot(x * D_k, dy') with bare bilinear factors
+        launch_prepare_units(st, nullptr, mu1, mu2, s, p->d.number_units_ignore, flags, p->bucket, false, ws.table_bare,
+                             ws.status);
+        if (p->algo_bwd == DAU_ALGO_TILED) {
+            tiled_dot_run(st, p->tiled_dot, x, dy, ws.filters + 1 * kFilterPlane, ws.table_bare, p->drop_col, p->drop_row,
+                          ws.r4, ws.tiled_dot);
+        } else {
+            launch_blur_direct(st, x, (long)s.N * s.S, s.H, s.W, ws.filters + 1 * kFilterPlane, kNumK, p->blur_k, ws.xk4);
+            launch_gather_dot_direct(st, ws.xk4, dy, ws.table_bare, s, p->drop_col, p->drop_row, ws.r4);
+        }
+        launch_finalize_grads(st, ws.r4, w, s, p->d.number_units_ignore, p->d.mu_learning_rate_factor, need_mask,
+                              flags & DAU_FLAG_SINGLE_DIM_KERNEL, dw, dmu1, dmu2, dsigma);
+    }
+    if (need_mask & DAU_NEED_DX) {
+        // input gradient: the forward gather on the mirrored-Gaussian-blurred error with the
+        // parameters read as [F,G,S] and negated offsets (base_dau_conv_layer.cu:299-325)
+        launch_prepare_units(st, w, mu1, mu2, s, 0, flags, p->bucket, true, ws.table_t,
+                             (need_mask & param_mask) ? nullptr : ws.status);
+        if (p->algo_fwd == DAU_ALGO_TILED) {
+            tiled_gather_run(st, p->tiled_dx, dy, ws.filters + 5 * kFilterPlane, ws.table_t, dx, ws.tiled_dx);
+        } else {
+            launch_blur_direct(st, dy, (long)s.N * s.F, s.H, s.W, ws.filters + 5 * kFilterPlane, 1, p->blur_k, ws.eb);
+            launch_gather_sum_direct(st, ws.eb, ws.table_t, s.N, s.F, s.S, s.G, s.H, s.W, dx);
+        }
+    }
+    DAU_HIP(hipPeekAtLastError());
+    return DAU_OK;
+}
+
+int dau_conv_check_status(const dau_conv_plan* p, void* stream, const void* workspace, float* max_abs_mu_out) {
+    if (!p || !workspace) return fail(DAU_INVALID_ARGUMENT, "null argument");
+    Status h;
+    DAU_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    DAU_HIP(hipMemcpy(&h, workspace, sizeof(Status), hipMemcpyDeviceToHost));
+    float mx;
+    std::memcpy(&mx, &h.max_abs_mu_bits, sizeof(float));
+    if (max_abs_mu_out) *max_abs_mu_out = mx;
+    if (h.nan_seen) return fail(DAU_FAILED_PRECONDITION, "DAUConvOp ERROR: got NaN value in offset (mu1,mu2) variable");
+    if (mx > (float)p->bucket)
+        return fail(DAU_INVALID_ARGUMENT,
+                    "DAUConvOp ERROR: actual offsets (%.3f) larger than what max_kernel_size=%d allows (setup max_kernel_size "
+                    "and dau_unit_border_bound correctly to avoid this)",
+                    mx, p->d.max_kernel_size);
+    return DAU_OK;
+}
+
+int dau_conv_filters(const dau_conv_plan* p, void* stream, const float* sigma, float* filters_out) {
+    if (!p || !sigma || !filters_out) return fail(DAU_INVALID_ARGUMENT, "null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // synthesise into a scratch with the fixed plane pitch, then compact to k*k planes
+    float* tmp = nullptr;
+    DAU_HIP(hipMalloc(&tmp, sizeof(float) * 6 * kFilterPlane));
+    launch_synth_filters(st, sigma, p->blur_k, p->d.flags, tmp);
+    const size_t plane = sizeof(float) * p->blur_k * p->blur_k;
+    hipError_t e = hipMemcpy2DAsync(filters_out, plane, tmp, sizeof(float) * kFilterPlane, plane, 6, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(DAU_INTERNAL, "dau_conv_filters: %s", hipGetErrorString(e));
+    return DAU_OK;
+}
+
+int dau_conv_unit_table(const dau_conv_plan* p, void* stream, const float* mu1, const float* mu2, int32_t* offsets_out,
+                        float* factors_out) {
+    if (!p || !mu1 || !mu2 || !offsets_out || !factors_out) return fail(DAU_INVALID_ARGUMENT, "null argument");
+    launch_unit_table_export(static_cast<hipStream_t>(stream), mu1, mu2, p->units(), p->d.flags, offsets_out, factors_out);
+    DAU_HIP(hipPeekAtLastError());
+    return DAU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,42 @@
+// Interface of the LDS-tiled kernels (DAU_ALGO_TILED).
+//   gather-sum (forward y and input gradient dx): MFMA 4x4x1 outer products with
+//     tap-separated accumulators over image-pair-interleaved LDS planes  (k_gather_mfma.hip)
+//   gather-dot (parameter gradients): lane-per-unit packed-FMA kernel     (k_gather_dot.hip)
+#pragma once
+#include "dau_common.hpp"
+
+namespace dau {
+
+// Geometry of one gather-sum pass  (in-channels Cin -> out-channels Cout).
+struct TiledConfig {
+    int N, Cin, Cout, G, H, W;
+    int R;            // offset bucket
+    int blur_k;       // prefilter support
+    int NP;           // image pairs = ceil(N/2)
+    int rows, pitch;  // staged plane: rows = H + 2R + 1, pitch (in positions) = W + 2R + 1 rounded so pitch % 32 == 8
+    int tiles_x, tiles_y;   // 8x8 position tiles covering (H+1) x (W+1)
+    int fblock;       // out-channels per workgroup
+    int variant;      // kernel instantiation id
+};
+
+bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, TiledConfig* cfg);
+size_t tiled_gather_workspace_bytes(const TiledConfig& cfg);
+// blur `in` ([N,Cin,H,W]) with `filter` (k*k taps at kFilterPlane pitch), stage it, gather into `out` ([N,Cout,H,W]).
+// `table` is indexed [Cin][G][Cout].
+void tiled_gather_run(hipStream_t st, const TiledConfig& cfg, const float* in, const float* filter,
+                      const UnitRef* table, float* out, void* workspace);
+
+struct TiledDotConfig {
+    Shape sh;
+    int R, blur_k;
+    int NP;
+    int variant;
+};
+
+bool tiled_dot_configure(const Shape& sh, int R, int blur_k, TiledDotConfig* cfg);
+size_t tiled_dot_workspace_bytes(const TiledDotConfig& cfg);
+// r4[k][s][g][f] = sum_{n,p} dy'[n,f,p] * bilinear(x * D_k, p + o);  filters4 = Dw,Dmu1,Dmu2,Dsigma planes.
+void tiled_dot_run(hipStream_t st, const TiledDotConfig& cfg, const float* x, const float* dy, const float* filters4,
+                   const UnitRef* table_bare, int drop_col, int drop_row, float* r4, void* workspace);
+
+}  // namespace dau

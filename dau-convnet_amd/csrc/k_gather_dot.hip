@@ -1,0 +1,7 @@
+#include "dau_tiled.hpp"
+namespace dau {
+bool tiled_dot_configure(const Shape&, int, int, TiledDotConfig*) { return false; }
+size_t tiled_dot_workspace_bytes(const TiledDotConfig&) { return 0; }
+void tiled_dot_run(hipStream_t, const TiledDotConfig&, const float*, const float*, const float*, const UnitRef*, int, int,
+                   float*, void*) {}
+}  // namespace dau

@@ -1,0 +1,192 @@
+"""ctypes binding of the C ABI in include/dau_conv.h (libdau_conv_hip.so).
+
+This is the only route from Python into the operator: there is no CPU or eager-PyTorch
+fallback.  If the HIP library is missing the import fails loudly.
+PyTorch is used for device memory and the current HIP stream only.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdau_conv_hip.so")
+
+DAU_OK, DAU_INVALID_ARGUMENT, DAU_FAILED_PRECONDITION, DAU_INTERNAL = 0, 1, 2, 3
+
+FLAG_USE_INTERPOLATION = 1 << 0
+FLAG_UNIT_TESTING = 1 << 1
+FLAG_SINGLE_DIM_KERNEL = 1 << 2
+FLAG_FORBID_POSITIVE_DIM1 = 1 << 3
+
+ALGO_AUTO, ALGO_DIRECT, ALGO_TILED = 0, 1, 2
+PASS_FORWARD, PASS_BACKWARD = 1, 2
+NEED_DX, NEED_DW, NEED_DMU1, NEED_DMU2, NEED_DSIGMA, NEED_ALL = 1, 2, 4, 8, 16, 31
+
+
+class DAUConvError(RuntimeError):
+    """Base class; .code holds the DAU_* status."""
+    code = DAU_INTERNAL
+
+
+class InvalidArgumentError(DAUConvError, ValueError):      # TF: errors.InvalidArgumentError
+    code = DAU_INVALID_ARGUMENT
+
+
+class FailedPreconditionError(DAUConvError):                # TF: errors.FailedPreconditionError
+    code = DAU_FAILED_PRECONDITION
+
+
+class InternalError(DAUConvError):                          # TF: errors.InternalError
+    code = DAU_INTERNAL
+
+
+class _Desc(ctypes.Structure):
+    _fields_ = [
+        ("struct_size", ctypes.c_int32), ("batch", ctypes.c_int32), ("in_channels", ctypes.c_int32),
+        ("out_channels", ctypes.c_int32), ("units_per_channel", ctypes.c_int32), ("height", ctypes.c_int32),
+        ("width", ctypes.c_int32), ("max_kernel_size", ctypes.c_int32), ("number_units_ignore", ctypes.c_int32),
+        ("flags", ctypes.c_int32), ("algo", ctypes.c_int32), ("sigma_hint", ctypes.c_float),
+        ("mu_learning_rate_factor", ctypes.c_float),
+    ]
+
+
+class _Info(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("offset_bucket", "blur_support", "algo_forward", "algo_backward", "drop_last_col", "drop_last_row")]
+
+
+def _load():
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(
+            "dau_conv: %s not found. Build it with `make -C dau-convnet_amd/csrc` (hipcc, gfx950) or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback." % _LIB_PATH)
+    lib = ctypes.CDLL(_LIB_PATH)
+    vp, fp, ip = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p
+    lib.dau_conv_abi_version.restype = ctypes.c_int
+    lib.dau_conv_last_error.restype = ctypes.c_char_p
+    lib.dau_conv_plan_create.argtypes = [ctypes.POINTER(_Desc), ctypes.POINTER(vp)]
+    lib.dau_conv_plan_destroy.argtypes = [vp]
+    lib.dau_conv_plan_get_info.argtypes = [vp, ctypes.POINTER(_Info)]
+    lib.dau_conv_workspace_bytes.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]
+    lib.dau_conv_forward.argtypes = [vp, vp, fp, fp, fp, fp, fp, fp, vp, ctypes.c_size_t]
+    lib.dau_conv_backward.argtypes = [vp, vp] + [fp] * 11 + [vp, ctypes.c_size_t, ctypes.c_int]
+    lib.dau_conv_check_status.argtypes = [vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
+    lib.dau_conv_filters.argtypes = [vp, vp, fp, fp]
+    lib.dau_conv_unit_table.argtypes = [vp, vp, fp, fp, ip, fp]
+    if lib.dau_conv_abi_version() != 1:
+        raise ImportError("dau_conv: ABI version mismatch in %s" % _LIB_PATH)
+    return lib
+
+
+lib = _load()
+
+
+def _check(code):
+    if code == DAU_OK:
+        return
+    msg = lib.dau_conv_last_error().decode("utf-8", "replace")
+    raise {DAU_INVALID_ARGUMENT: InvalidArgumentError, DAU_FAILED_PRECONDITION: FailedPreconditionError}.get(
+        code, InternalError)(msg)
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, name, shape=None):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise InvalidArgumentError("%s must be a contiguous float32 tensor on the GPU" % name)
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise InvalidArgumentError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+    return t
+
+
+class Plan(object):
+    """Owns one dau_conv_plan plus lazily allocated workspaces (one per pass)."""
+
+    def __init__(self, N, S, F, G, H, W, max_kernel_size=9, number_units_ignore=0, flags=FLAG_USE_INTERPOLATION,
+                 algo=ALGO_AUTO, sigma_hint=0.5, mu_learning_rate_factor=1.0):
+        d = _Desc(ctypes.sizeof(_Desc), N, S, F, G, H, W, int(max_kernel_size), int(number_units_ignore), int(flags),
+                  int(algo), float(sigma_hint), float(mu_learning_rate_factor))
+        self._h = ctypes.c_void_p()
+        _check(lib.dau_conv_plan_create(ctypes.byref(d), ctypes.byref(self._h)))
+        self.N, self.S, self.F, self.G, self.H, self.W = N, S, F, G, H, W
+        info = _Info()
+        _check(lib.dau_conv_plan_get_info(self._h, ctypes.byref(info)))
+        self.info = {n: getattr(info, n) for n, _ in _Info._fields_}
+        self._ws = {}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            lib.dau_conv_plan_destroy(h)
+            self._h = None
+
+    def workspace_bytes(self, which):
+        n = ctypes.c_size_t()
+        _check(lib.dau_conv_workspace_bytes(self._h, which, ctypes.byref(n)))
+        return n.value
+
+    def _workspace(self, which, device):
+        key = (which, device)
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = torch.empty(self.workspace_bytes(which), dtype=torch.uint8, device=device)
+            self._ws[key] = ws
+        return ws
+
+    def forward(self, x, w, mu1, mu2, sigma):
+        pshape = (1, self.S, self.G, self.F)
+        _req(x, "input", (self.N, self.S, self.H, self.W))
+        for t, n in ((w, "weights"), (mu1, "mu1"), (mu2, "mu2"), (sigma, "sigma")):
+            _req(t, n, pshape)
+        y = torch.empty((self.N, self.F, self.H, self.W), dtype=torch.float32, device=x.device)
+        ws = self._workspace(PASS_FORWARD, x.device)
+        _check(lib.dau_conv_forward(self._h, _stream(), _ptr(x), _ptr(w), _ptr(mu1), _ptr(mu2), _ptr(sigma), _ptr(y),
+                                    _ptr(ws), ws.numel()))
+        self._last_ws = ws
+        return y
+
+    def backward(self, x, dy, w, mu1, mu2, sigma, need_mask=NEED_ALL):
+        pshape = (1, self.S, self.G, self.F)
+        _req(x, "input", (self.N, self.S, self.H, self.W))
+        _req(dy, "grad", (self.N, self.F, self.H, self.W))
+        for t, n in ((w, "weights"), (mu1, "mu1"), (mu2, "mu2"), (sigma, "sigma")):
+            _req(t, n, pshape)
+        dev = x.device
+        new = lambda shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        dx = new(x.shape) if need_mask & NEED_DX else None
+        dw = new(pshape) if need_mask & NEED_DW else None
+        dmu1 = new(pshape) if need_mask & NEED_DMU1 else None
+        dmu2 = new(pshape) if need_mask & NEED_DMU2 else None
+        dsigma = new(pshape) if need_mask & NEED_DSIGMA else None
+        ws = self._workspace(PASS_BACKWARD, dev)
+        _check(lib.dau_conv_backward(self._h, _stream(), _ptr(x), _ptr(dy), _ptr(w), _ptr(mu1), _ptr(mu2), _ptr(sigma),
+                                     _ptr(dx), _ptr(dw), _ptr(dmu1), _ptr(dmu2), _ptr(dsigma), _ptr(ws), ws.numel(),
+                                     int(need_mask)))
+        self._last_ws = ws
+        return dx, dw, dmu1, dmu2, dsigma
+
+    def check_status(self):
+        """Sync + raise if the last call saw NaN or out-of-bucket offsets; returns max(|mu|)."""
+        mx = ctypes.c_float()
+        _check(lib.dau_conv_check_status(self._h, _stream(), _ptr(self._last_ws), ctypes.byref(mx)))
+        return mx.value
+
+    def filters(self, sigma):
+        k = self.info["blur_support"]
+        out = torch.empty((6, k, k), dtype=torch.float32, device=sigma.device)
+        _check(lib.dau_conv_filters(self._h, _stream(), _ptr(sigma), _ptr(out)))
+        return out
+
+    def unit_table(self, mu1, mu2):
+        units = self.S * self.G * self.F
+        off = torch.empty((units, 2), dtype=torch.int32, device=mu1.device)
+        fac = torch.empty((units, 4), dtype=torch.float32, device=mu1.device)
+        _check(lib.dau_conv_unit_table(self._h, _stream(), _ptr(mu1), _ptr(mu2), _ptr(off), _ptr(fac)))
+        return off, fac

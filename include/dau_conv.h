@@ -1,0 +1,161 @@
+/*
+ * dau_conv.h -- C ABI of the MI355X-native DAU convolution operator.
+ *
+ * This is the drop-in boundary for the reference's DAU forward/backward path.  Every
+ * entry point takes plain device pointers, sizes and a HIP stream handle; there are no
+ * framework types in the signatures.  What each entry point replaces in
+ * skokec/DAU-ConvNet (paths relative to the reference tree):
+ *
+ *   dau_conv_plan_create / _destroy   BaseDAUConvLayer::LayerSetUp + Reshape
+ *                                     (src/dau_conv/base_dau_conv_layer.cpp:29-187,190-394),
+ *                                     DAUConvForward / DAUConvBackward constructors
+ *                                     (src/dau_conv/dau_conv_impl/dau_conv_forward.cpp:28-77,
+ *                                      dau_conv_backward.cpp:11-89), DAUConvSettings
+ *                                     (include/dau_conv/base_dau_conv_layer.hpp:109-130)
+ *   dau_conv_workspace_bytes          DAUConvForward::get_allocation_sizes
+ *                                     (include/dau_conv/dau_conv_impl/dau_conv_forward.hpp:30-33),
+ *                                     DAUConvBackward::get_allocation_sizes (dau_conv_backward.hpp:41-42),
+ *                                     allocate_workspace_mem (base_dau_conv_layer.hpp:263)
+ *   dau_conv_forward                  DAUConvOp::Compute (plugins/tensorflow/src/dau_conv_op.cpp:150-324)
+ *                                     -> BaseDAUConvLayer::Forward_gpu (src/dau_conv/base_dau_conv_layer.cu:15-127)
+ *                                     -> DAUConvForward::forward_pass (dau_conv_forward.cpp:128-174)
+ *   dau_conv_backward                 DAUConvGradOp::Compute (plugins/tensorflow/src/dau_conv_grad_op.cpp:115-318)
+ *                                     -> BaseDAUConvLayer::Backward_gpu (base_dau_conv_layer.cu:130-363)
+ *                                     -> DAUConvBackward::backward_pass (dau_conv_backward.cpp:173-232)
+ *   dau_conv_check_status             the max|mu| / NaN precondition checks of the ops
+ *                                     (dau_conv_op.cpp:223-262, dau_conv_grad_op.cpp:209-250); done on the
+ *                                     device without a host sync, read back only on request
+ *   dau_conv_filters                  BaseDAUKernelCompute::get_kernels (base_dau_conv_layer.cu:537-710)
+ *   dau_conv_unit_table               perpare_weights_and_offsets (dau_conv_forward_core.hpp:1858-2215)
+ *   dau_conv_last_error               DAUException::what (include/dau_conv/util/common.hpp:40-66)
+ *
+ * Tensor layouts (identical to the reference): activations NCHW contiguous float32;
+ * parameters and their gradients [1,S,G,F] contiguous float32 (f fastest); sigma is a
+ * full [1,S,G,F] tensor whose element 0 is used (base_dau_conv_layer.hpp:266-275).
+ *
+ * Ownership: the caller owns every buffer, including one workspace per in-flight call.
+ * A plan is immutable after creation, so concurrent calls on different streams with
+ * different workspaces are safe.  No call allocates, frees or synchronises, except
+ * dau_conv_check_status (which waits for the stream).  dau_conv_backward OVERWRITES
+ * the gradient outputs (the reference op zero-fills them and then accumulates,
+ * dau_conv_grad_op.cpp:202-205 -- same net result).
+ */
+#ifndef DAU_CONV_H_
+#define DAU_CONV_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DAU_CONV_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define DAU_API __attribute__((visibility("default")))
+#else
+#define DAU_API
+#endif
+
+/* Status codes; they map 1:1 onto the TensorFlow codes the reference ops raise. */
+enum {
+    DAU_OK = 0,
+    DAU_INVALID_ARGUMENT = 1,    /* bad shape/attr, |mu| larger than the offset bucket allows   */
+    DAU_FAILED_PRECONDITION = 2, /* NaN in mu1/mu2, sigma <= 0                                   */
+    DAU_INTERNAL = 3             /* HIP runtime error (reference: DAUException -> INTERNAL)      */
+};
+
+/* dau_conv_desc.flags */
+enum {
+    DAU_FLAG_USE_INTERPOLATION = 1 << 0,    /* attr use_interpolation (default true)              */
+    DAU_FLAG_UNIT_TESTING = 1 << 1,         /* attr unit_testing: drop last error row/col per the
+                                               oracle rule (dau_conv_test.py:110-136)             */
+    DAU_FLAG_SINGLE_DIM_KERNEL = 1 << 2,    /* attr single_dim_kernel (DAUConv1d)                 */
+    DAU_FLAG_FORBID_POSITIVE_DIM1 = 1 << 3, /* attr forbid_positive_dim1                          */
+    DAU_FLAG_DEFAULT = DAU_FLAG_USE_INTERPOLATION
+};
+
+/* dau_conv_desc.algo */
+enum {
+    DAU_ALGO_AUTO = 0,      /* fastest kernels that support the shape                            */
+    DAU_ALGO_DIRECT = 1,    /* plain one-thread-per-output HIP kernels (any shape)               */
+    DAU_ALGO_TILED = 2      /* LDS-tiled MFMA gather / wave-reduced gradient kernels             */
+};
+
+/* which pass a workspace is sized for */
+enum { DAU_PASS_FORWARD = 1, DAU_PASS_BACKWARD = 2 };
+
+/* dau_conv_backward need-mask (params_propagate_down of Backward_gpu) */
+enum {
+    DAU_NEED_DX = 1 << 0,
+    DAU_NEED_DW = 1 << 1,
+    DAU_NEED_DMU1 = 1 << 2,
+    DAU_NEED_DMU2 = 1 << 3,
+    DAU_NEED_DSIGMA = 1 << 4,
+    DAU_NEED_ALL = 31
+};
+
+typedef struct dau_conv_desc {
+    int32_t struct_size;            /* sizeof(dau_conv_desc), for ABI evolution                   */
+    int32_t batch;                  /* N                                                          */
+    int32_t in_channels;            /* S                                                          */
+    int32_t out_channels;           /* F  (attr num_output)                                       */
+    int32_t units_per_channel;      /* G  (number_units_x * number_units_y, incl. ignored units)  */
+    int32_t height, width;          /* H, W (output size == input size, dau_conv_op.cpp:185-188)  */
+    int32_t max_kernel_size;        /* attr kernel_size: 9/17/33/65 -> offset bucket 4/8/16/32    */
+    int32_t number_units_ignore;    /* attr number_units_ignore                                   */
+    int32_t flags;                  /* DAU_FLAG_*                                                 */
+    int32_t algo;                   /* DAU_ALGO_*                                                 */
+    float sigma_hint;               /* host copy of sigma; sizes the blur support 2*ceil(5s)+1 as
+                                       LayerSetUp does (base_dau_conv_layer.cpp:140-147); the taps
+                                       themselves are computed from the device tensor each call   */
+    float mu_learning_rate_factor;  /* attr mu_learning_rate_factor (grad op only)                */
+} dau_conv_desc;
+
+typedef struct dau_conv_plan dau_conv_plan; /* opaque */
+
+typedef struct dau_conv_plan_info {
+    int32_t offset_bucket;     /* R in {4,8,16,32}                                                */
+    int32_t blur_support;      /* k of the k x k prefilter                                        */
+    int32_t algo_forward;      /* DAU_ALGO_* actually used by dau_conv_forward / the dx pass      */
+    int32_t algo_backward;     /* DAU_ALGO_* actually used for the parameter gradients            */
+    int32_t drop_last_col;     /* unit_testing edge rule outcome for this W                       */
+    int32_t drop_last_row;     /* ... and H                                                       */
+} dau_conv_plan_info;
+
+DAU_API int dau_conv_abi_version(void);
+DAU_API const char *dau_conv_last_error(void); /* thread-local message of the last failing call */
+
+DAU_API int dau_conv_plan_create(const dau_conv_desc *desc, dau_conv_plan **plan_out);
+DAU_API int dau_conv_plan_destroy(dau_conv_plan *plan);
+DAU_API int dau_conv_plan_get_info(const dau_conv_plan *plan, dau_conv_plan_info *info);
+DAU_API int dau_conv_workspace_bytes(const dau_conv_plan *plan, int pass, size_t *bytes_out);
+
+/* stream is a hipStream_t (NULL = default stream).  All pointers are device pointers. */
+DAU_API int dau_conv_forward(const dau_conv_plan *plan, void *stream, const float *x, const float *w,
+                     const float *mu1, const float *mu2, const float *sigma, float *y,
+                     void *workspace, size_t workspace_bytes);
+
+DAU_API int dau_conv_backward(const dau_conv_plan *plan, void *stream, const float *x, const float *dy,
+                      const float *w, const float *mu1, const float *mu2, const float *sigma,
+                      float *dx, float *dw, float *dmu1, float *dmu2, float *dsigma,
+                      void *workspace, size_t workspace_bytes, int need_mask);
+
+/* Waits for `stream`, then reports what the last call that used `workspace` found in mu1/mu2:
+ * DAU_OK, DAU_FAILED_PRECONDITION (NaN) or DAU_INVALID_ARGUMENT (|mu| beyond the bucket).
+ * max_abs_mu_out (may be NULL) receives max(|mu1|,|mu2|). */
+DAU_API int dau_conv_check_status(const dau_conv_plan *plan, void *stream, const void *workspace,
+                          float *max_abs_mu_out);
+
+/* Building blocks exposed for parity tests (device pointers in and out).
+ * filters_out: 6 planes of k*k floats in the order Gn, Dw, Dmu1, Dmu2, Dsigma, Gerr.
+ * unit table: offsets_out[2*u] = floor(mu1), [2*u+1] = floor(mu2); factors_out[4*u + 2*dy + dx]. */
+DAU_API int dau_conv_filters(const dau_conv_plan *plan, void *stream, const float *sigma, float *filters_out);
+DAU_API int dau_conv_unit_table(const dau_conv_plan *plan, void *stream, const float *mu1, const float *mu2,
+                        int32_t *offsets_out, float *factors_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAU_CONV_H_ */

@@ -1,0 +1,180 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors of the
+reference's numpy oracle and against the C oracle on seeded inputs.
+
+Tolerance (north star): 1e-4 relative, fp32, with an absolute floor of 1e-6 of the tensor's
+max-norm; per-unit offset/fraction bookkeeping is bit-exact.
+The reference's own tests drop the last output column before comparing
+(dau_conv_test.py:398-404); this implementation is exact there, so nothing is dropped.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dau_oracle as orc
+from util import assert_parity, case_kernel_size, golden_cases, load_case
+
+pytestmark = pytest.mark.gpu
+
+ALGOS = {"direct": 1, "auto": 0}
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _flags(c, capi):
+    f = 0
+    if int(c["use_interpolation"]): f |= capi.FLAG_USE_INTERPOLATION
+    if int(c["unit_testing"]): f |= capi.FLAG_UNIT_TESTING
+    if int(c["single_dim_kernel"]): f |= capi.FLAG_SINGLE_DIM_KERNEL
+    if int(c["forbid_positive_dim1"]): f |= capi.FLAG_FORBID_POSITIVE_DIM1
+    return f
+
+
+def _run_case(c, algo, lr=1.0):
+    from dau_conv import _capi
+    N, S, H, W = c["x"].shape
+    _, _, G, F = c["w"].shape
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=case_kernel_size(c), number_units_ignore=int(c["ignore"]),
+                      flags=_flags(c, _capi), algo=algo, sigma_hint=float(c["sigma"]), mu_learning_rate_factor=lr)
+    x, w, mu1, mu2, dy = (_dev(c[k]) for k in ("x", "w", "mu1", "mu2", "dy"))
+    sigma = torch.full((1, S, G, F), float(c["sigma"]), device="cuda")
+    y = plan.forward(x, w, mu1, mu2, sigma)
+    plan.check_status()
+    dx, dw, dmu1, dmu2, dsigma = plan.backward(x, dy, w, mu1, mu2, sigma)
+    plan.check_status()
+    torch.cuda.synchronize()
+    out = dict(y=y, dx=dx, dw=dw, dmu1=dmu1, dmu2=dmu2, dsigma=dsigma)
+    return plan, {k: v.cpu().numpy() for k, v in out.items()}
+
+
+@pytest.mark.parametrize("algo", sorted(ALGOS))
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_vectors(name, algo):
+    """Every golden case of the reference oracle, forward + all five gradients."""
+    c = load_case(name)
+    _, got = _run_case(c, ALGOS[algo])
+    for key in ("y", "dx", "dw", "dmu1", "dmu2", "dsigma"):
+        # golden values carry the numpy oracle's own float32 accumulation error (~1e-6 of max-norm)
+        assert_parity(got[key], c[key], "%s/%s/%s" % (name, algo, key), rel=1e-4, floor=3e-6)
+
+
+def test_mu_learning_rate_factor_and_need_mask():
+    """dmu1/dmu2 are scaled inside the op (dau_conv_grad_op.cpp:297-303); skipped outputs stay None."""
+    from dau_conv import _capi
+    c = load_case("k9_16x16_g4")
+    _, base = _run_case(c, 0, lr=1.0)
+    _, got = _run_case(c, 0, lr=1000.0)
+    assert_parity(got["dmu1"], base["dmu1"] * 1000.0, "dmu1*lr", rel=1e-6, floor=1e-7)
+    assert_parity(got["dmu2"], base["dmu2"] * 1000.0, "dmu2*lr", rel=1e-6, floor=1e-7)
+    assert_parity(got["dw"], base["dw"], "dw", rel=0, floor=0)
+    assert_parity(got["dsigma"], base["dsigma"], "dsigma", rel=0, floor=0)
+    N, S, H, W = c["x"].shape
+    _, _, G, F = c["w"].shape
+    plan = _capi.Plan(N, S, F, G, H, W, flags=_capi.FLAG_USE_INTERPOLATION | _capi.FLAG_UNIT_TESTING)
+    sigma = torch.full((1, S, G, F), 0.5, device="cuda")
+    out = plan.backward(_dev(c["x"]), _dev(c["dy"]), _dev(c["w"]), _dev(c["mu1"]), _dev(c["mu2"]), sigma,
+                        need_mask=_capi.NEED_DX | _capi.NEED_DW)
+    assert out[2] is None and out[3] is None and out[4] is None
+    assert_parity(out[0].cpu().numpy(), base["dx"], "dx only", rel=0, floor=0)
+    assert_parity(out[1].cpu().numpy(), base["dw"], "dw only", rel=1e-6, floor=1e-7)
+
+
+def test_unit_bookkeeping_bit_exact():
+    """floor(mu), fractions and the four bilinear factors are bit-identical to the oracle."""
+    from dau_conv import _capi
+    rs = np.random.RandomState(3)
+    S, G, F = 5, 4, 24
+    mu1 = rs.uniform(-8, 8, (1, S, G, F)).astype(np.float32)
+    mu2 = rs.uniform(-8, 8, (1, S, G, F)).astype(np.float32)
+    mu1.flat[:6] = [-8.0, 8.0, 7.99, -7.99, -0.0, 3.0]
+    mu2.flat[:6] = [8.0, -8.0, -7.99, 7.99, 1e-8, -3.0]
+    for interp in (True, False):
+        plan = _capi.Plan(1, S, F, G, 8, 8, max_kernel_size=17, flags=_capi.FLAG_USE_INTERPOLATION if interp else 0)
+        off, fac = plan.unit_table(_dev(mu1), _dev(mu2))
+        eoff, efac = orc.unit_table(mu1, mu2, use_interpolation=interp)
+        assert np.array_equal(off.cpu().numpy(), eoff)
+        assert np.array_equal(fac.cpu().numpy().view(np.uint32), efac.view(np.uint32))
+
+
+@pytest.mark.parametrize("sigma,sd,fp", [(0.5, 0, 0), (0.8, 0, 0), (1.2, 0, 0), (0.5, 1, 0), (0.5, 1, 1)])
+def test_filter_synthesis(sigma, sd, fp):
+    from dau_conv import _capi
+    flags = _capi.FLAG_USE_INTERPOLATION | (_capi.FLAG_SINGLE_DIM_KERNEL if sd else 0) | (_capi.FLAG_FORBID_POSITIVE_DIM1 if fp else 0)
+    plan = _capi.Plan(1, 1, 1, 2, 8, 8, flags=flags, sigma_hint=sigma)
+    k = plan.info["blur_support"]
+    assert k == orc.filter_support(sigma)
+    got = plan.filters(torch.full((1, 1, 2, 1), sigma, device="cuda")).cpu().numpy()
+    want = orc.filters(sigma, k=k, single_dim_kernel=sd, forbid_positive_dim1=fp)
+    for i, name in enumerate(("Gn", "Dw", "Dmu1", "Dmu2", "Dsigma", "Gerr")):
+        assert_parity(got[i], want[name], name, rel=1e-6, floor=1e-7)
+
+
+def test_error_convention():
+    """NaN offsets -> FAILED_PRECONDITION, offsets beyond the kernel -> INVALID_ARGUMENT
+    (dau_conv_op.cpp:250-262); wrong shapes are rejected before any launch."""
+    from dau_conv import _capi
+    N, S, F, G, H, W = 1, 2, 4, 2, 8, 8
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9)
+    x = torch.rand(N, S, H, W, device="cuda")
+    w = torch.randn(1, S, G, F, device="cuda")
+    mu = torch.zeros(1, S, G, F, device="cuda")
+    sigma = torch.full((1, S, G, F), 0.5, device="cuda")
+    plan.forward(x, w, mu, mu, sigma)
+    assert plan.check_status() == 0.0
+    bad = mu.clone(); bad[0, 1, 1, 2] = float("nan")
+    plan.forward(x, w, bad, mu, sigma)
+    with pytest.raises(_capi.FailedPreconditionError):
+        plan.check_status()
+    far = mu.clone(); far[0, 0, 0, 0] = 6.5
+    y = plan.forward(x, w, mu, far, sigma)
+    with pytest.raises(_capi.InvalidArgumentError):
+        plan.check_status()
+    assert torch.isfinite(y).all()
+    with pytest.raises(_capi.InvalidArgumentError):
+        plan.forward(x[:, :1], w, mu, mu, sigma)
+    with pytest.raises(_capi.InvalidArgumentError):
+        plan.forward(x, w[..., :2], mu, mu, sigma)
+
+
+@pytest.mark.parametrize("shape", [
+    # shape matrix of the reference tests (dau_conv_test.py:418-465), channel counts reduced so the
+    # CPU oracle finishes in seconds: patch splitting W=65/H=8, small batches, 9/17 kernels, odd S,
+    # 6x6 images, large kernels
+    dict(N=2, W=65, H=8, S=33, F=32, G=2, k=9, m=3),
+    dict(N=1, W=8, H=8, S=32, F=32, G=2, k=9, m=3),
+    dict(N=4, W=32, H=32, S=8, F=32, G=4, k=9, m=3),
+    dict(N=4, W=32, H=32, S=8, F=32, G=4, k=17, m=6),
+    dict(N=4, W=32, H=32, S=3, F=32, G=4, k=17, m=3),
+    dict(N=4, W=6, H=6, S=16, F=64, G=2, k=17, m=8),
+    dict(N=2, W=64, H=64, S=3, F=32, G=4, k=33, m=10),
+    dict(N=2, W=64, H=64, S=4, F=16, G=4, k=65, m=20),
+    # shapes of the benchmark configs at reduced N / channels
+    dict(N=2, W=27, H=27, S=12, F=32, G=4, k=9, m=3),
+    dict(N=3, W=56, H=56, S=8, F=32, G=4, k=9, m=3),
+    dict(N=2, W=28, H=28, S=16, F=16, G=4, k=9, m=3),
+])
+@pytest.mark.parametrize("algo", sorted(ALGOS))
+def test_seeded_shapes_against_c_oracle(shape, algo):
+    from dau_conv import _capi
+    rs = np.random.RandomState(7)
+    N, S, F, G, H, W, k, m = (shape[q] for q in ("N", "S", "F", "G", "H", "W", "k", "m"))
+    # distributions of dau_conv_test.py:342-368
+    x = rs.rand(N, S, H, W).astype(np.float32)
+    w = (rs.randn(1, S, G, F) * 0.1).astype(np.float32)
+    lim = k // 2 - 0.01  # the layer clips mu to +-(floor(k/2) - border) (dau_conv.py:183,190-191)
+    mu1 = np.clip(rs.uniform(-m, m, (1, S, G, F)), -lim, lim).astype(np.float32)
+    mu2 = np.clip(rs.uniform(-m, m, (1, S, G, F)), -lim, lim).astype(np.float32)
+    dy = rs.randn(N, F, H, W).astype(np.float32)
+    lr = 1000.0
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, flags=_capi.FLAG_USE_INTERPOLATION | _capi.FLAG_UNIT_TESTING,
+                      algo=ALGOS[algo], sigma_hint=0.5, mu_learning_rate_factor=lr)
+    sigma = torch.full((1, S, G, F), 0.5, device="cuda")
+    y = plan.forward(_dev(x), _dev(w), _dev(mu1), _dev(mu2), sigma)
+    got = plan.backward(_dev(x), _dev(dy), _dev(w), _dev(mu1), _dev(mu2), sigma)
+    plan.check_status()
+    want_y = orc.forward(x, w, mu1, mu2, 0.5)
+    want = orc.backward(x, dy, w, mu1, mu2, 0.5, unit_testing=True, mu_learning_rate_factor=lr)
+    assert_parity(y.cpu().numpy(), want_y, "y")
+    for t, key in zip(got, ("dx", "dw", "dmu1", "dmu2", "dsigma")):
+        assert_parity(t.cpu().numpy(), want[key], key)
