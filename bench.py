@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Benchmark of the DAU forward+backward hot path (BASELINE.json metric: GSamples/s = N*H*W / (t_fwd+t_bwd)).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = dau_conv_forward + dau_conv_backward (dx, dw, dmu1, dmu2, dsigma) over one synthetic batch that is
+already resident in HBM, plus -- for N>1 -- the RCCL all-reduce of the four parameter-gradient tensors.  The batch
+is sharded over ranks (weak scaling: 128 images per GPU).  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline      dominant kernel's ALGORITHMIC FLOPs per launch / its average launch time, measured live with HIP
+                events on the launch stream (dau_conv_profile_begin/_end).  The operator is compute bound (1640 FLOP/B
+                at this shape), so the roof is the fp32 matrix/vector peak of 157.3 TFLOP/s.
+  cpu_baseline  the CPU oracle (oracle/dau_oracle.c, OpenMP) timed on this box's host cores on a small slice of the
+                same workload.  A reported baseline, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "dau-convnet_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+WORKLOADS = {
+    # north star of BASELINE.json: N=128 C=256->256 HW=56, 4-unit DAU, fp32, max_kernel_size 9, mu ~ U(-3,3)
+    "ns": dict(N=128, S=256, F=256, H=56, W=56, G=4, k=9, m=3.0,
+               label="north-star N=128/GPU C=256->256 HW=56 G=4(2x2) k=9 mu~U(-3,3) sigma=0.5 fp32 fwd+bwd(dx,dw,dmu1,dmu2,dsigma)"),
+    # AlexNet-DAU conv2 shape (configs[1])
+    "c1": dict(N=64, S=96, F=256, H=27, W=27, G=4, k=9, m=3.0,
+               label="AlexNet-DAU conv2 N=64/GPU C=96->256 HW=27 G=4 k=9 fp32 fwd+bwd"),
+    "small": dict(N=8, S=32, F=32, H=56, W=56, G=4, k=9, m=3.0, label="smoke-size N=8 C=32->32 HW=56 G=4"),
+}
+FP32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
+    ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 direct, 2 tiled")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the operator)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from dau_conv import _capi
+
+    wl = WORKLOADS[args.workload]
+    N, S, F, H, W, G, k, m = (wl[q] for q in ("N", "S", "F", "H", "W", "G", "k", "m"))
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    pgen = torch.Generator(device=dev)
+    pgen.manual_seed(99)                       # parameters are replicated: same seed on every rank
+    # distributions of the reference tests (dau_conv_test.py:342-368)
+    x = torch.rand((N, S, H, W), device=dev, generator=gen)
+    dy = torch.randn((N, F, H, W), device=dev, generator=gen)
+    w = torch.randn((1, S, G, F), device=dev, generator=pgen) * 0.1
+    lim = k // 2 - 0.01
+    mu1 = ((torch.rand((1, S, G, F), device=dev, generator=pgen) * 2 - 1) * m).clamp_(-lim, lim)
+    mu2 = ((torch.rand((1, S, G, F), device=dev, generator=pgen) * 2 - 1) * m).clamp_(-lim, lim)
+    sigma = torch.full((1, S, G, F), 0.5, device=dev)
+
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, flags=_capi.FLAG_USE_INTERPOLATION, algo=args.algo,
+                      sigma_hint=0.5, mu_learning_rate_factor=1.0)
+    flat = torch.empty(4 * S * G * F, device=dev) if world > 1 else None
+
+    def step():
+        y = plan.forward(x, w, mu1, mu2, sigma)
+        dx, dw, dmu1, dmu2, dsigma = plan.backward(x, dy, w, mu1, mu2, sigma)
+        if world > 1:
+            # batch-sharded data parallelism: one all-reduce of [dw, dmu1, dmu2, dsigma] over RCCL/xGMI
+            torch.cat([dw.reshape(-1), dmu1.reshape(-1), dmu2.reshape(-1), dsigma.reshape(-1)], out=flat)
+            dist.all_reduce(flat)
+        return y, dx
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    plan.check_status()
+    fence()
+    plan.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = plan.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    samples = float(N) * world * H * W * args.steps
+    value = samples / elapsed / 1e9
+    # algorithmic FLOPs per launch: 4 MAC per (n,px,s,g,f) for each gather-sum, 8 MAC for gather-dot
+    unit_px = float(G) * N * H * W * S * F
+    flops = {"gather_sum_fwd": 8.0 * unit_px, "gather_sum_dx": 8.0 * unit_px, "gather_dot": 16.0 * unit_px}
+    kern = {}
+    for name, (ms, launches) in prof.items():
+        if launches:
+            avg = ms / launches
+            kern[name] = dict(avg_ms=round(avg, 4), launches=launches, tflops=round(flops[name] / (avg * 1e-3) / 1e12, 2))
+    dominant = max(kern, key=lambda n: kern[n]["avg_ms"]) if kern else None
+    roofline = None
+    if dominant:
+        ach = flops[dominant] / (kern[dominant]["avg_ms"] * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel=dominant, achieved=round(ach, 2), peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / FP32_PEAK_TFLOPS, 4), traffic=None, kernels=kern,
+                        whole_step_tflops=round(32.0 * unit_px * args.steps / elapsed / 1e12, 2))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import dau_oracle as orc
+        ncpu = 2 if N >= 2 else 1
+        xs, dys = x[:ncpu].cpu().numpy(), dy[:ncpu].cpu().numpy()
+        wn, m1, m2 = w.cpu().numpy(), mu1.cpu().numpy(), mu2.cpu().numpy()
+        orc.forward(xs[:1, :4], wn[:, :4], m1[:, :4], m2[:, :4], 0.5)   # load + warm the library
+        c0 = time.perf_counter()
+        orc.forward(xs, wn, m1, m2, 0.5)
+        orc.backward(xs, dys, wn, m1, m2, 0.5, unit_testing=False, mu_learning_rate_factor=1.0)
+        ct = time.perf_counter() - c0
+        cpu = dict(value=round(ncpu * H * W / ct / 1e9, 8), unit="GSamples/s", cores=orc.num_threads(), kind="port",
+                   sample="oracle fwd+bwd on the first %d images of the same batch (%.1f s); double accumulation, OpenMP" % (ncpu, ct))
+
+    if rank == 0:
+        out = dict(metric="DAU fwd+bwd GSamples/s (N*H*W/s)", value=round(value, 6), unit="GSamples/s", n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload=wl["label"], global_batch=N * world, parallelism="dp%d" % world,
+                               algo_forward=plan.info["algo_forward"], algo_backward=plan.info["algo_backward"]),
+                   roofline=roofline, cpu_baseline=cpu)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

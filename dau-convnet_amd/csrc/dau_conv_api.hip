@@ -10,6 +10,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "dau_common.hpp"
 #include "dau_tiled.hpp"
@@ -73,9 +75,37 @@ struct dau_conv_plan {
     TiledConfig tiled_dx;    // gather-sum dx : F -> S
     TiledDotConfig tiled_dot;
     long units() const { return (long)sh.S * sh.G * sh.F; }
+    // optional benchmark timing (dau_conv_profile_begin/_end); mutable because the passes take a const plan
+    mutable bool profiling = false;
+    mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[DAU_PROFILE_SLOTS];
+    mutable size_t prof_used[DAU_PROFILE_SLOTS] = {0, 0, 0};
 };
 
 namespace {
+
+// event bracket around one dominant kernel launch when profiling is on
+struct ProfScope {
+    const dau_conv_plan* p;
+    int slot;
+    hipStream_t st;
+    hipEvent_t stop = nullptr;
+    ProfScope(const dau_conv_plan* plan, int slot_, hipStream_t st_) : p(plan), slot(slot_), st(st_) {
+        if (!p->profiling) return;
+        auto& pool = p->prof_events[slot];
+        size_t& used = p->prof_used[slot];
+        if (used == pool.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            pool.emplace_back(a, b);
+        }
+        (void)hipEventRecord(pool[used].first, st);
+        stop = pool[used].second;
+        ++used;
+    }
+    ~ProfScope() {
+        if (stop) (void)hipEventRecord(stop, st);
+    }
+};
 
 struct FwdWs {
     Status* status;
@@ -199,7 +229,36 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
 }
 
 int dau_conv_plan_destroy(dau_conv_plan* plan) {
+    if (plan)
+        for (auto& pool : plan->prof_events)
+            for (auto& ev : pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete plan;
+    return DAU_OK;
+}
+
+int dau_conv_profile_begin(dau_conv_plan* plan) {
+    if (!plan) return fail(DAU_INVALID_ARGUMENT, "null argument");
+    for (size_t& u : plan->prof_used) u = 0;
+    plan->profiling = true;
+    return DAU_OK;
+}
+
+int dau_conv_profile_end(dau_conv_plan* plan, double* ms_out, int32_t* launches_out) {
+    if (!plan || !ms_out || !launches_out) return fail(DAU_INVALID_ARGUMENT, "null argument");
+    plan->profiling = false;
+    for (int slot = 0; slot < DAU_PROFILE_SLOTS; ++slot) {
+        double total = 0.0;
+        for (size_t i = 0; i < plan->prof_used[slot]; ++i) {
+            auto& ev = plan->prof_events[slot][i];
+            DAU_HIP(hipEventSynchronize(ev.second));
+            float ms = 0.0f;
+            DAU_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+            total += ms;
+        }
+        ms_out[slot] = total;
+        launches_out[slot] = (int32_t)plan->prof_used[slot];
+        plan->prof_used[slot] = 0;
+    }
     return DAU_OK;
 }
 
@@ -234,9 +293,12 @@ int dau_conv_forward(const dau_conv_plan* p, void* stream, const float* x, const
     launch_synth_filters(st, sigma, p->blur_k, p->d.flags, ws.filters);
     launch_prepare_units(st, w, mu1, mu2, s, p->d.number_units_ignore, p->d.flags, p->bucket, false, ws.table, ws.status);
     if (p->algo_fwd == DAU_ALGO_TILED) {
-        tiled_gather_run(st, p->tiled_fwd, x, ws.filters + 0 * kFilterPlane, ws.table, y, ws.tiled);
+        tiled_gather_prepare(st, p->tiled_fwd, x, ws.filters + 0 * kFilterPlane, ws.table, ws.tiled);
+        ProfScope prof(p, 0, st);
+        tiled_gather_run(st, p->tiled_fwd, y, ws.tiled);
     } else {
         launch_blur_direct(st, x, (long)s.N * s.S, s.H, s.W, ws.filters + 0 * kFilterPlane, 1, p->blur_k, ws.xb);
+        ProfScope prof(p, 0, st);
         launch_gather_sum_direct(st, ws.xb, ws.table, s.N, s.S, s.F, s.G, s.H, s.W, y);
     }
     DAU_HIP(hipPeekAtLastError());
@@ -266,10 +328,13 @@ int dau_conv_backward(const dau_conv_plan* p, void* stream, const float* x, cons
         launch_prepare_units(st, nullptr, mu1, mu2, s, p->d.number_units_ignore, flags, p->bucket, false, ws.table_bare,
                              ws.status);
         if (p->algo_bwd == DAU_ALGO_TILED) {
-            tiled_dot_run(st, p->tiled_dot, x, dy, ws.filters + 1 * kFilterPlane, ws.table_bare, p->drop_col, p->drop_row,
-                          ws.r4, ws.tiled_dot);
+            tiled_dot_prepare(st, p->tiled_dot, x, dy, ws.filters + 1 * kFilterPlane, ws.table_bare, p->drop_col,
+                              p->drop_row, ws.tiled_dot);
+            ProfScope prof(p, 2, st);
+            tiled_dot_run(st, p->tiled_dot, ws.r4, ws.tiled_dot);
         } else {
             launch_blur_direct(st, x, (long)s.N * s.S, s.H, s.W, ws.filters + 1 * kFilterPlane, kNumK, p->blur_k, ws.xk4);
+            ProfScope prof(p, 2, st);
             launch_gather_dot_direct(st, ws.xk4, dy, ws.table_bare, s, p->drop_col, p->drop_row, ws.r4);
         }
         launch_finalize_grads(st, ws.r4, w, s, p->d.number_units_ignore, p->d.mu_learning_rate_factor, need_mask,
@@ -281,9 +346,12 @@ int dau_conv_backward(const dau_conv_plan* p, void* stream, const float* x, cons
         launch_prepare_units(st, w, mu1, mu2, s, 0, flags, p->bucket, true, ws.table_t,
                              (need_mask & param_mask) ? nullptr : ws.status);
         if (p->algo_fwd == DAU_ALGO_TILED) {
-            tiled_gather_run(st, p->tiled_dx, dy, ws.filters + 5 * kFilterPlane, ws.table_t, dx, ws.tiled_dx);
+            tiled_gather_prepare(st, p->tiled_dx, dy, ws.filters + 5 * kFilterPlane, ws.table_t, ws.tiled_dx);
+            ProfScope prof(p, 1, st);
+            tiled_gather_run(st, p->tiled_dx, dx, ws.tiled_dx);
         } else {
             launch_blur_direct(st, dy, (long)s.N * s.F, s.H, s.W, ws.filters + 5 * kFilterPlane, 1, p->blur_k, ws.eb);
+            ProfScope prof(p, 1, st);
             launch_gather_sum_direct(st, ws.eb, ws.table_t, s.N, s.F, s.S, s.G, s.H, s.W, dx);
         }
     }

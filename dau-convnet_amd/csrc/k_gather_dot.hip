@@ -2,6 +2,7 @@
 namespace dau {
 bool tiled_dot_configure(const Shape&, int, int, TiledDotConfig*) { return false; }
 size_t tiled_dot_workspace_bytes(const TiledDotConfig&) { return 0; }
-void tiled_dot_run(hipStream_t, const TiledDotConfig&, const float*, const float*, const float*, const UnitRef*, int, int,
-                   float*, void*) {}
+void tiled_dot_prepare(hipStream_t, const TiledDotConfig&, const float*, const float*, const float*, const UnitRef*, int, int,
+                       void*) {}
+void tiled_dot_run(hipStream_t, const TiledDotConfig&, float*, void*) {}
 }  // namespace dau

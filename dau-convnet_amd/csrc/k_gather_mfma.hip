@@ -1,6 +1,479 @@
+// Tiled gather-sum on the matrix cores: forward output and input gradient.
+//
+//   out[n,f,y,x] = sum_{c,g} sum_{t in 2x2 taps} w_t(c,g,f) * Xb[n,c, y+oy+dy_t, x+ox+dx_t]
+//
+// Replaces the reference's DAUConv_forward_pipeline_kernel + interleave_input_data_kernel +
+// perpare_weights_and_offsets (include/dau_conv/dau_conv_impl/dau_conv_forward_core.hpp:804-1605,
+// 1607-1732, 1858-2215) and the prefilter pass caffe_gpu_convolve2 (src/dau_conv/util/convolve.cu:48-131).
+// It is a different algorithm, designed for CDNA4:
+//
+//  * Tap-separated accumulation.  For a unit u=(c,g,f) with integer displacement o_u, ONE value
+//    Xb[q+o_u] feeds all four bilinear taps:  Z_t[q] += w_t(u) * Xb[q+o_u]  (t = 0..3), and the output
+//    is assembled once per (n,f) at the end:  out[p] = Z_0[p] + Z_1[p+(0,1)] + Z_2[p+(1,0)] + Z_3[p+(1,1)].
+//    So the inner loop needs one LDS float per four MACs, at any (unaligned) displacement.
+//  * The four MACs are one row of v_mfma_f32_4x4x1_16b_f32: a lane's own X value is the B operand, the
+//    four tap weights sit in the four lanes of its quad as the A operand (lane 4b+i holds w_i), and
+//    D register i of lane 4b+j accumulates Z_i for that lane's position.  Exact fp32 FMA numerics.
+//  * Two images are interleaved element-wise in the staged planes, so one ds_read_b64 (256 B/clk LDS
+//    rate, naturally aligned whatever the displacement) feeds two MFMAs.
+//  * Positions are grouped in 8x8 tiles whose LDS addresses differ from the lane base by compile-time
+//    immediates; the staged plane pitch is = 8 (mod 32) positions so every ds_read_b64 of a tile is
+//    bank-conflict free.  The (H+1)x(W+1) domain of Z needs one extra row/column: two "edge" tiles.
+//  * A workgroup owns (image pair, FB output channels) and streams all input channels through a
+//    double-buffered LDS plane filled by global_load_lds (no VGPR staging) from a pre-blurred,
+//    zero-bordered, pair-interleaved copy written by blur_pack_kernel.
+#include <type_traits>
+#include <utility>
+
 #include "dau_tiled.hpp"
+
 namespace dau {
-bool tiled_gather_configure(int, int, int, int, int, int, int, int, TiledConfig*) { return false; }
-size_t tiled_gather_workspace_bytes(const TiledConfig&) { return 0; }
-void tiled_gather_run(hipStream_t, const TiledConfig&, const float*, const float*, const UnitRef*, float*, void*) {}
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* glb_ptr_t;
+
+namespace {
+
+constexpr int kFB = 4;            // output channels per workgroup
+constexpr int kUnitDwords = 8;    // packed unit: {w00,off,w01,off,w10,off,w11,off}
+
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Geometry {
+    int H, W, R;
+    int rows, pitch;          // staged plane
+    int tx, ty;               // regular 8x8 tiles
+    int edge;                 // 1: W%8==0 && H%8==0 -> separate edge tiles; 0: regular tiles cover (H+1)x(W+1)
+    size_t plane_bytes;       // padded to 1 KiB (one global_load_lds wave instruction)
+};
+
+Geometry make_geometry(int H, int W, int R) {
+    Geometry g{};
+    g.H = H; g.W = W; g.R = R;
+    g.edge = (H % 8 == 0 && W % 8 == 0) ? 1 : 0;
+    g.tx = g.edge ? W / 8 : (W + 1 + 7) / 8;
+    g.ty = g.edge ? H / 8 : (H + 1 + 7) / 8;
+    const int need_cols = (g.edge ? W + 1 : g.tx * 8) + 2 * R;
+    const int need_rows = (g.edge ? H + 1 : g.ty * 8) + 2 * R;
+    int pitch = need_cols;
+    while (pitch % 32 != 8) ++pitch;
+    g.pitch = pitch;
+    g.rows = need_rows;
+    g.plane_bytes = round_up((size_t)g.rows * g.pitch * 8, 1024);
+    return g;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// blur + pack: in[N,C,H,W] -> staged[NP][C][rows][pitch][2] (zero border of R on the left/top,
+// >= R+1 on the right/bottom), blurred with the k x k filter.  One workgroup per (pair, channel).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) blur_pack_kernel(const float* __restrict__ in, const float* __restrict__ filt,
+                                                        int N, int C, int H, int W, int R, int k, int rows,
+                                                        int pitch, size_t plane_floats, float* __restrict__ staged) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int np = blockIdx.x / C, c = blockIdx.x % C;
+    const int kr = (k - 1) / 2;
+    const int lw = W + 2 * kr;                 // LDS row width (positions), both images interleaved
+    const int lh = H + 2 * kr;
+    // raw planes with a zero halo of the blur radius, interleaved [y][x][2]
+    for (int t = threadIdx.x; t < lh * lw; t += blockDim.x) {
+        const int yy = t / lw - kr, xx = t % lw - kr;
+        float a = 0.0f, b = 0.0f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const int n0 = 2 * np, n1 = 2 * np + 1;
+            a = in[(((long)n0 * C + c) * H + yy) * W + xx];
+            if (n1 < N) b = in[(((long)n1 * C + c) * H + yy) * W + xx];
+        }
+        lds[2 * t] = a; lds[2 * t + 1] = b;
+    }
+    __syncthreads();
+    float* out = staged + ((size_t)np * C + c) * plane_floats;
+    const f2* l2 = reinterpret_cast<const f2*>(lds);
+    for (int t = threadIdx.x; t < rows * pitch; t += blockDim.x) {
+        const int row = t / pitch, col = t % pitch;
+        const int yy = row - R, xx = col - R;
+        f2 acc = {0.0f, 0.0f};
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            for (int j = 0; j < k; ++j)
+                for (int i = 0; i < k; ++i) {
+                    const float fv = filt[j * k + i];          // wave-uniform -> scalar load
+                    const f2 v = l2[(yy + j) * lw + xx + i];
+                    acc.x = fmaf(fv, v.x, acc.x);
+                    acc.y = fmaf(fv, v.y, acc.y);
+                }
+        }
+        reinterpret_cast<f2*>(out)[t] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// unit packing: UnitRef[Cin][G][Cout] -> packed[FBn][Cin] slices of [G][kFB][8 dwords], each slice padded to 1 KiB
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_units_kernel(const UnitRef* __restrict__ table, int Cin, int G, int Cout, int pitch,
+                                  int ut_stride_dwords, unsigned int* __restrict__ packed) {
+    const int nfb = (Cout + kFB - 1) / kFB;
+    const long total = (long)nfb * Cin * G * kFB;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int fi = (int)(idx % kFB);
+        const int g = (int)((idx / kFB) % G);
+        const int c = (int)((idx / ((long)kFB * G)) % Cin);
+        const int fb = (int)(idx / ((long)kFB * G * Cin));
+        const int f = fb * kFB + fi;
+        UnitRef u{0, 0, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (f < Cout) u = table[((long)c * G + g) * Cout + f];
+        const int off = (u.oy * pitch + u.ox) * 8;   // byte displacement inside a staged plane
+        unsigned int* dst = packed + ((long)fb * Cin + c) * ut_stride_dwords + (g * kFB + fi) * kUnitDwords;
+        dst[0] = __float_as_uint(u.w00); dst[1] = (unsigned)off;
+        dst[2] = __float_as_uint(u.w01); dst[3] = (unsigned)off;
+        dst[4] = __float_as_uint(u.w10); dst[5] = (unsigned)off;
+        dst[6] = __float_as_uint(u.w11); dst[7] = (unsigned)off;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// main kernel
+// ------------------------------------------------------------------------------------------------
+struct GatherArgs {
+    const char* staged;        // [NP][Cin][plane_bytes]
+    const char* packed;        // [NFB][Cin][ut_stride]
+    float* out;                // [N][Cout][H][W]
+    int N, Cin, Cout, G, H, W, R;
+    int nfb;                   // ceil(Cout / kFB)
+    unsigned plane_bytes, ut_stride;
+    unsigned zpitch;           // epilogue Z-plane pitch (floats)
+};
+
+// TX, TY : regular 8x8 tiles;  PITCH: staged pitch (positions);  EDGE: two extra edge tiles
+// SPLIT  : waves sharing one output channel (tiles are dealt out in contiguous ranges)
+template <int TX, int TY, int PITCH, bool EDGE, int SPLIT>
+struct GatherTraits {
+    static constexpr int kRegular = TX * TY;
+    static constexpr int kTiles = kRegular + (EDGE ? 2 : 0);
+    static constexpr int kPerPart = (kTiles + SPLIT - 1) / SPLIT;
+    static constexpr int kWaves = kFB * SPLIT;
+    static constexpr int kThreads = kWaves * 64;
+    static constexpr int kEpiF = 2;   // output channels assembled per epilogue round
+};
+
+template <int TX, int PITCH>
+__device__ __forceinline__ constexpr unsigned tile_imm(int tile) {
+    return (unsigned)(((tile / TX) * 8 * PITCH + (tile % TX) * 8) * 8);
+}
+
+// One unit for one part: every tile index (hence every LDS immediate) is a compile-time constant.
+// Tiles go in batches of B: the ds_read_b64 of batch b+1 are issued before the MFMAs of batch b and the
+// wait is counted (lgkmcnt = size of batch b+1), so one batch is always in flight.  The reads are
+// inline asm on purpose: hipcc would fuse pairs into ds_read2_b64, which runs at half the LDS rate,
+// and waits lgkmcnt(0) for the prefetched batch.  The sched_barrier after each wait keeps the
+// register-only MFMAs from being hoisted above it.
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+constexpr int kBatch = 4;   // tiles per batch
+
+template <class T, int TX, int PITCH, int TILE>
+__device__ __forceinline__ void load_tile(f2& dst, unsigned addr, unsigned addr_e0, unsigned addr_e1) {
+    if constexpr (TILE < T::kRegular)
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(tile_imm<TX, PITCH>(TILE)) : "memory");
+    else if constexpr (TILE == T::kRegular)
+        asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr_e0) : "memory");
+    else if constexpr (TILE == T::kRegular + 1)
+        asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr_e1) : "memory");
+}
+
+template <class T, int TX, int PITCH, int FIRST, int COUNT, int BATCH, int... J>
+__device__ __forceinline__ void load_batch(f2 (&dst)[kBatch], unsigned addr, unsigned addr_e0, unsigned addr_e1,
+                                           std::integer_sequence<int, J...>) {
+    (([&] {
+         if constexpr (BATCH * kBatch + J < COUNT)
+             load_tile<T, TX, PITCH, FIRST + BATCH * kBatch + J>(dst[J], addr, addr_e0, addr_e1);
+     }()),
+     ...);
+}
+
+template <class T, int TX, int PITCH, int FIRST, int COUNT, int KP, int BATCH>
+__device__ __forceinline__ void unit_batches(f4 (&acc)[KP][2], f2 (&xv)[2][kBatch], float wv, unsigned addr,
+                                             unsigned addr_e0, unsigned addr_e1) {
+    constexpr int NB = (COUNT + kBatch - 1) / kBatch;
+    constexpr int left = COUNT - (BATCH + 1) * kBatch;
+    constexpr int next = (BATCH + 1 < NB) ? (left < kBatch ? left : kBatch) : 0;
+    if constexpr (BATCH + 1 < NB)
+        load_batch<T, TX, PITCH, FIRST, COUNT, BATCH + 1>(xv[(BATCH + 1) & 1], addr, addr_e0, addr_e1,
+                                                          std::make_integer_sequence<int, kBatch>{});
+    lds_wait<next>();
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+        const int i = BATCH * kBatch + j;
+        if (i < COUNT) {
+            acc[i][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv, xv[BATCH & 1][j].x, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv, xv[BATCH & 1][j].y, acc[i][1], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (BATCH + 1 < NB) unit_batches<T, TX, PITCH, FIRST, COUNT, KP, BATCH + 1>(acc, xv, wv, addr, addr_e0, addr_e1);
+}
+
+template <int TX, int TY, int PITCH, bool EDGE, int SPLIT, int PART, int KP>
+__device__ __forceinline__ void unit_step(f4 (&acc)[KP][2], float wv, unsigned addr, unsigned addr_e0,
+                                          unsigned addr_e1) {
+    using T = GatherTraits<TX, TY, PITCH, EDGE, SPLIT>;
+    constexpr int first = PART * T::kPerPart;
+    constexpr int count = (first + KP <= T::kTiles) ? KP : (T::kTiles > first ? T::kTiles - first : 0);
+    if constexpr (count > 0) {
+        f2 xv[2][kBatch];
+        load_batch<T, TX, PITCH, first, count, 0>(xv[0], addr, addr_e0, addr_e1, std::make_integer_sequence<int, kBatch>{});
+        unit_batches<T, TX, PITCH, first, count, KP, 0>(acc, xv, wv, addr, addr_e0, addr_e1);
+    }
+}
+
+// Whole per-wave program for one PART (the part only selects which tiles the wave owns, so that all
+// LDS immediates are compile-time constants; every wave runs the same number of barriers).
+template <int TX, int TY, int PITCH, bool EDGE, int SPLIT, int PART>
+__device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int lane, int wave, int fi) {
+    using T = GatherTraits<TX, TY, PITCH, EDGE, SPLIT>;
+    constexpr int KP = T::kPerPart;
+
+    // workgroup -> (image pair, channel block); blocks that share an image pair are made consecutive
+    // on one XCD (blocks b and b+8 share an XCD) so the staged planes are fetched into one L2.
+    const int nblk = gridDim.x;
+    int logical;
+    {
+        const int xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+        const int chunk = nblk / 8, rem = nblk % 8;
+        logical = (xcd < rem ? xcd * (chunk + 1) : rem * (chunk + 1) + (xcd - rem) * chunk) + idx;
+    }
+    const int np = logical / a.nfb, fb = logical % a.nfb;
+
+    const int R = a.R, H = a.H, W = a.W;
+    const int ly = lane >> 3, lx = lane & 7;
+    const unsigned lane_base = (unsigned)(((ly + R) * PITCH + (lx + R)) * 8);
+    // edge tiles: the column x = W (y = 0..H) followed by the row y = H (x = 0..W-1)
+    int ey[2] = {0, 0}, ex[2] = {0, 0};
+    bool evalid[2] = {false, false};
+    if (EDGE) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = e * 64 + lane;
+            if (idx <= H) { ey[e] = idx; ex[e] = W; evalid[e] = true; }
+            else if (idx < H + 1 + W) { ey[e] = H; ex[e] = idx - (H + 1); evalid[e] = true; }
+        }
+    }
+    const unsigned ebase0 = (unsigned)(((ey[0] + R) * PITCH + ex[0] + R) * 8);
+    const unsigned ebase1 = (unsigned)(((ey[1] + R) * PITCH + ex[1] + R) * 8);
+
+    const unsigned plane_bytes = a.plane_bytes, ut_stride = a.ut_stride;
+    const char* src_planes = a.staged + (size_t)np * a.Cin * plane_bytes;
+    const char* src_units = a.packed + (size_t)fb * a.Cin * ut_stride;
+    const unsigned ut_base = 2 * plane_bytes;
+
+    auto issue = [&](int c, int buf) {
+        const char* ps = src_planes + (size_t)c * plane_bytes;
+        const unsigned pieces = plane_bytes >> 10;
+        for (unsigned piece = wave; piece < pieces; piece += T::kWaves)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(ps + (size_t)piece * 1024 + lane * 16),
+                                             (lds_ptr_t)(smem + buf * plane_bytes + piece * 1024), 16, 0, 0);
+        const char* us = src_units + (size_t)c * ut_stride;
+        const unsigned upieces = ut_stride >> 10;
+        for (unsigned piece = wave; piece < upieces; piece += T::kWaves)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(us + (size_t)piece * 1024 + lane * 16),
+                                             (lds_ptr_t)(smem + ut_base + buf * ut_stride + piece * 1024), 16, 0, 0);
+    };
+
+    f4 acc[KP][2];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) { acc[i][0] = f4{0, 0, 0, 0}; acc[i][1] = f4{0, 0, 0, 0}; }
+
+    issue(0, 0);
+    for (int c = 0; c < a.Cin; ++c) {
+        const int buf = c & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // plane c is in LDS for everyone; everyone is done reading plane c-1
+        if (c + 1 < a.Cin) issue(c + 1, buf ^ 1);
+        const unsigned pbase = buf * plane_bytes;
+        const char* ut = smem + ut_base + buf * ut_stride + (fi * kUnitDwords + (lane & 3) * 2) * 4;
+        const unsigned ut_addr = (unsigned)(ut - smem);
+        f2 wo;
+        asm volatile("ds_read_b64 %0, %1" : "=v"(wo) : "v"(ut_addr) : "memory");
+        for (int g = 0; g < a.G; ++g) {
+            lds_wait<0>();
+            const float wv = wo.x;
+            const unsigned off = __float_as_uint(wo.y) + pbase;
+            // next unit's {weight, displacement} is fetched under this unit's MFMAs
+            if (g + 1 < a.G)
+                asm volatile("ds_read_b64 %0, %1" : "=v"(wo) : "v"(ut_addr + (g + 1) * (kFB * kUnitDwords * 4)) : "memory");
+            unit_step<TX, TY, PITCH, EDGE, SPLIT, PART, KP>(acc, wv, lane_base + off, ebase0 + off, ebase1 + off);
+        }
+    }
+
+    // ---- epilogue: out[p] = Z0[p] + Z1[p+(0,1)] + Z2[p+(1,0)] + Z3[p+(1,1)] through LDS ---------------
+    const unsigned zpitch = a.zpitch;
+    const unsigned zplane = (unsigned)(H + 1) * zpitch;       // floats per tap plane
+    float* zs = reinterpret_cast<float*>(smem);
+    const long HW = (long)H * W;
+#pragma unroll
+    for (int img = 0; img < 2; ++img) {   // unrolled: acc[i][img] must be a static register index
+#pragma unroll 1
+        for (int fh = 0; fh < kFB / T::kEpiF; ++fh) {
+            __syncthreads();
+            if (fi / T::kEpiF == fh) {
+                float* zf = zs + (size_t)(fi % T::kEpiF) * 4 * zplane;
+#pragma unroll
+                for (int i = 0; i < KP; ++i) {
+                    constexpr int first = PART * KP;
+                    const int tile = first + i;
+                    int y, x; bool ok;
+                    if (tile < T::kRegular) { y = (tile / TX) * 8 + ly; x = (tile % TX) * 8 + lx; ok = (y <= H) && (x <= W); }
+                    else if (tile == T::kRegular) { y = ey[0]; x = ex[0]; ok = evalid[0]; }
+                    else if (tile == T::kRegular + 1) { y = ey[1]; x = ex[1]; ok = evalid[1]; }
+                    else { y = 0; x = 0; ok = false; }
+                    if (ok) {
+                        const f4 v = acc[i][img];
+                        float* q = zf + (unsigned)y * zpitch + x;
+                        q[0] = v[0]; q[zplane] = v[1]; q[2 * zplane] = v[2]; q[3 * zplane] = v[3];
+                    }
+                }
+            }
+            __syncthreads();
+            const int n = 2 * np + img;
+            for (long o = threadIdx.x; o < (long)T::kEpiF * HW; o += T::kThreads) {
+                const int fl = (int)(o / HW);
+                const int p = (int)(o % HW), y = p / W, x = p % W;
+                const int f = fb * kFB + fh * T::kEpiF + fl;
+                const float* zf = zs + (size_t)fl * 4 * zplane + (unsigned)y * zpitch + x;
+                const float v = zf[0] + zf[zplane + 1] + zf[2 * zplane + zpitch] + zf[3 * zplane + zpitch + 1];
+                if (n < a.N && f < a.Cout) a.out[((long)n * a.Cout + f) * HW + p] = v;
+            }
+        }
+    }
+}
+
+template <int TX, int TY, int PITCH, bool EDGE, int SPLIT>
+__global__ void __launch_bounds__(kFB * SPLIT * 64) gather_mfma_kernel(const GatherArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int part = wave % SPLIT, fi = wave / SPLIT;
+    if (SPLIT == 1 || part == 0) gather_body<TX, TY, PITCH, EDGE, SPLIT, 0>(a, smem, lane, wave, fi);
+    else if (SPLIT == 2 || part == 1) { if constexpr (SPLIT > 1) gather_body<TX, TY, PITCH, EDGE, SPLIT, 1>(a, smem, lane, wave, fi); }
+    else if (SPLIT == 3 || part == 2) { if constexpr (SPLIT > 2) gather_body<TX, TY, PITCH, EDGE, SPLIT, 2>(a, smem, lane, wave, fi); }
+    else { if constexpr (SPLIT > 3) gather_body<TX, TY, PITCH, EDGE, SPLIT, 3>(a, smem, lane, wave, fi); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Variant { int tx, ty, pitch, edge, split; };
+// instantiated geometries (add rows here and in dispatch below)
+const Variant kVariants[] = {
+    {7, 7, 72, 1, 2},    // 56x56, R=4
+    {7, 7, 104, 1, 2},   // 56x56, R=8/16
+    {4, 4, 72, 1, 1},    // 32x32
+    {2, 2, 40, 1, 1},    // 16x16
+    {3, 3, 40, 1, 1},    // 24x24
+    {1, 1, 40, 1, 1},    // 8x8
+    {4, 4, 40, 0, 1},    // 25..31 square-ish (27x27, 28x28), R=4
+};
+
+template <int TX, int TY, int PITCH, bool EDGE, int SPLIT>
+void launch_variant(hipStream_t st, const GatherArgs& a, int grid, size_t lds) {
+    using T = GatherTraits<TX, TY, PITCH, EDGE, SPLIT>;
+    auto kern = gather_mfma_kernel<TX, TY, PITCH, EDGE, SPLIT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::kThreads), lds, st, a);
+}
+
+size_t ut_stride_bytes(int G) { return round_up((size_t)G * kFB * kUnitDwords * 4, 1024); }
+
+size_t lds_bytes(const TiledConfig& c, const Geometry& g) {
+    const size_t main_b = 2 * g.plane_bytes + 2 * ut_stride_bytes(c.G);
+    const size_t zpitch = c.W + 2;
+    const size_t epi_b = (size_t)2 /*kEpiF*/ * 4 * (c.H + 1) * zpitch * 4;
+    return main_b > epi_b ? main_b : epi_b;
+}
+
+}  // namespace
+
+bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, TiledConfig* cfg) {
+    const Geometry g = make_geometry(H, W, R);
+    int variant = -1;
+    for (size_t i = 0; i < sizeof(kVariants) / sizeof(kVariants[0]); ++i)
+        if (kVariants[i].tx == g.tx && kVariants[i].ty == g.ty && kVariants[i].pitch == g.pitch && kVariants[i].edge == g.edge) {
+            variant = (int)i;
+            break;
+        }
+    if (variant < 0) return false;
+    TiledConfig c{};
+    c.N = N; c.Cin = Cin; c.Cout = Cout; c.G = G; c.H = H; c.W = W; c.R = R; c.blur_k = blur_k;
+    c.NP = (N + 1) / 2;
+    c.rows = g.rows; c.pitch = g.pitch; c.tiles_x = g.tx; c.tiles_y = g.ty; c.fblock = kFB; c.variant = variant;
+    if (lds_bytes(c, g) > 160 * 1024) return false;
+    // blur_pack stages both raw planes (+ blur halo) in LDS
+    const size_t blur_lds = (size_t)(H + blur_k - 1) * (W + blur_k - 1) * 8;
+    if (blur_lds > 64 * 1024) return false;
+    *cfg = c;
+    return true;
+}
+
+size_t tiled_gather_workspace_bytes(const TiledConfig& c) {
+    const Geometry g = make_geometry(c.H, c.W, c.R);
+    const size_t nfb = (c.Cout + kFB - 1) / kFB;
+    return round_up((size_t)c.NP * c.Cin * g.plane_bytes, 256) + round_up(nfb * c.Cin * ut_stride_bytes(c.G), 256);
+}
+
+void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in, const float* filter,
+                          const UnitRef* table, void* workspace) {
+    const Geometry g = make_geometry(c.H, c.W, c.R);
+    char* staged = static_cast<char*>(workspace);
+    char* packed = staged + round_up((size_t)c.NP * c.Cin * g.plane_bytes, 256);
+    const size_t blur_lds = (size_t)(c.H + c.blur_k - 1) * (c.W + c.blur_k - 1) * 8;
+    hipLaunchKernelGGL(blur_pack_kernel, dim3(c.NP * c.Cin), dim3(256), blur_lds, st, in, filter, c.N, c.Cin, c.H, c.W,
+                       c.R, c.blur_k, g.rows, g.pitch, g.plane_bytes / 4, reinterpret_cast<float*>(staged));
+    const int nfb = (c.Cout + kFB - 1) / kFB;
+    const size_t uts = ut_stride_bytes(c.G);
+    // packed slices are padded to whole KiB; zero the padding once per call together with the payload
+    (void)hipMemsetAsync(packed, 0, (size_t)nfb * c.Cin * uts, st);
+    const long total = (long)nfb * c.Cin * c.G * kFB;
+    const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    hipLaunchKernelGGL(pack_units_kernel, dim3(grid), dim3(256), 0, st, table, c.Cin, c.G, c.Cout, g.pitch, (int)(uts / 4),
+                       reinterpret_cast<unsigned int*>(packed));
+}
+
+void tiled_gather_run(hipStream_t st, const TiledConfig& c, float* out, void* workspace) {
+    const Geometry g = make_geometry(c.H, c.W, c.R);
+    GatherArgs a{};
+    a.staged = static_cast<const char*>(workspace);
+    a.packed = a.staged + round_up((size_t)c.NP * c.Cin * g.plane_bytes, 256);
+    a.out = out;
+    a.N = c.N; a.Cin = c.Cin; a.Cout = c.Cout; a.G = c.G; a.H = c.H; a.W = c.W; a.R = c.R;
+    a.nfb = (c.Cout + kFB - 1) / kFB;
+    a.plane_bytes = (unsigned)g.plane_bytes;
+    a.ut_stride = (unsigned)ut_stride_bytes(c.G);
+    a.zpitch = (unsigned)(c.W + 2);
+    const int grid = c.NP * a.nfb;
+    const size_t lds = lds_bytes(c, g);
+    switch (c.variant) {
+        case 0: launch_variant<7, 7, 72, true, 2>(st, a, grid, lds); break;
+        case 1: launch_variant<7, 7, 104, true, 2>(st, a, grid, lds); break;
+        case 2: launch_variant<4, 4, 72, true, 1>(st, a, grid, lds); break;
+        case 3: launch_variant<2, 2, 40, true, 1>(st, a, grid, lds); break;
+        case 4: launch_variant<3, 3, 40, true, 1>(st, a, grid, lds); break;
+        case 5: launch_variant<1, 1, 40, true, 1>(st, a, grid, lds); break;
+        case 6: launch_variant<4, 4, 40, false, 1>(st, a, grid, lds); break;
+        default: break;
+    }
+}
+
 }  // namespace dau

@@ -74,6 +74,8 @@ def _load():
     lib.dau_conv_check_status.argtypes = [vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
     lib.dau_conv_filters.argtypes = [vp, vp, fp, fp]
     lib.dau_conv_unit_table.argtypes = [vp, vp, fp, fp, ip, fp]
+    lib.dau_conv_profile_begin.argtypes = [vp]
+    lib.dau_conv_profile_end.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]
     if lib.dau_conv_abi_version() != 1:
         raise ImportError("dau_conv: ABI version mismatch in %s" % _LIB_PATH)
     return lib
@@ -177,6 +179,16 @@ class Plan(object):
         mx = ctypes.c_float()
         _check(lib.dau_conv_check_status(self._h, _stream(), _ptr(self._last_ws), ctypes.byref(mx)))
         return mx.value
+
+    def profile_begin(self):
+        _check(lib.dau_conv_profile_begin(self._h))
+
+    def profile_end(self):
+        """-> {slot name: (summed ms, launches)} for the dominant kernels since profile_begin()."""
+        ms = (ctypes.c_double * 3)()
+        n = (ctypes.c_int32 * 3)()
+        _check(lib.dau_conv_profile_end(self._h, ms, n))
+        return {name: (ms[i], n[i]) for i, name in enumerate(("gather_sum_fwd", "gather_sum_dx", "gather_dot"))}
 
     def filters(self, sigma):
         k = self.info["blur_support"]

@@ -155,6 +155,16 @@ DAU_API int dau_conv_filters(const dau_conv_plan *plan, void *stream, const floa
 DAU_API int dau_conv_unit_table(const dau_conv_plan *plan, void *stream, const float *mu1, const float *mu2,
                         int32_t *offsets_out, float *factors_out);
 
+/* Optional per-kernel timing for benchmarks (no reference counterpart; the reference only has the
+ * compile-time PROFILE_CUDA block, dau_conv_forward_core.hpp:2506-2563).  Between _begin and _end every
+ * dominant kernel launch is bracketed by HIP events on the caller's stream (asynchronous, no host sync).
+ * Slots: 0 = gather-sum of dau_conv_forward, 1 = gather-sum of the dx pass, 2 = gather-dot (parameter
+ * gradients).  _end waits for the events and returns summed milliseconds and launch counts per slot.
+ * Not thread-safe; one profiling session per plan at a time. */
+enum { DAU_PROFILE_SLOTS = 3 };
+DAU_API int dau_conv_profile_begin(dau_conv_plan *plan);
+DAU_API int dau_conv_profile_end(dau_conv_plan *plan, double *ms_out, int32_t *launches_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,14 @@ def test_golden_vectors(name, algo):
         assert_parity(got[key], c[key], "%s/%s/%s" % (name, algo, key), rel=1e-4, floor=3e-6)
 
 
+def test_tiled_kernels_are_selected_for_benchmark_shapes():
+    """AUTO must pick the LDS-tiled MFMA gather for the shapes the benchmark runs (no silent slow path)."""
+    from dau_conv import _capi
+    for (H, W, k) in ((56, 56, 9), (32, 32, 9), (32, 32, 17), (16, 16, 9), (8, 8, 9), (27, 27, 9), (28, 28, 9), (24, 24, 9)):
+        info = _capi.Plan(2, 4, 8, 2, H, W, max_kernel_size=k).info
+        assert info["algo_forward"] == _capi.ALGO_TILED, (H, W, k, info)
+
+
 def test_mu_learning_rate_factor_and_need_mask():
     """dmu1/dmu2 are scaled inside the op (dau_conv_grad_op.cpp:297-303); skipped outputs stay None."""
     from dau_conv import _capi
