@@ -1,8 +1,499 @@
+// Tiled gather-dot: parameter gradients
+//
+//   r_k[s,g,f] = sum_{n,y,x} E'[n,f,y,x] * sum_{dy,dx} b_{dy,dx}(s,g,f) * Xk[n,s, y+oy+dy, x+ox+dx],   k = w, mu1, mu2, sigma
+//
+// Replaces the reference's DAUConv_bwd_multi_pipeline_kernel + interleave_input_data_kernel +
+// interleave_error_data_kernel + perpare_weights_and_offsets_bw_multi
+// (include/dau_conv/dau_conv_impl/dau_conv_backward_core.hpp:1017-1820, 2248-2380, 2118-2246, 1824-2115)
+// and the 4-filter prefilter pass (src/dau_conv/util/convolve.cu:48-131).  Different algorithm:
+//
+//  * Re-indexed over the position q of the prefiltered input:
+//        r_k[u] = sum_{n,q} Xk[n,s,q] * Et_u[n,f,q],   Et_u[q] = sum_{dy,dx} b_{dy,dx} E'[q - o_u - (dy,dx)]
+//    so the error is interpolated once (4 MACs) and multiplied by the four k-planes (4 MACs): 8 MACs
+//    per (n, q, unit), the minimum (dau_conv_backward_core.hpp:846-975 does the same split).
+//  * LANE = UNIT.  A wave owns one input channel s and one pair of units g; its 64 lanes are the two
+//    units x 32 output channels.  Every lane keeps its own four accumulators for the whole kernel, so
+//    there is no cross-lane reduction (the reference needs cub::WarpReduce + atomics, :1747-1811).
+//  * The position q is wave-uniform: Xk[n,s,q] (4 kinds x 2 images = 32 B) arrives by SCALAR loads and
+//    feeds v_pk_fma_f32 as an SGPR pair; the error tile sits in LDS position-major with the 32 output
+//    channels fastest ([row][col][f][image]), so lane f always hits bank pair f: conflict-free
+//    ds_read_b64 at ANY per-lane displacement.
+//  * Two images are interleaved element-wise, so every packed FMA operand is a natural register pair
+//    (image n, image n+1); the bilinear factors are broadcast with op_sel.  8 v_pk_fma_f32 per position.
+//  * A workgroup owns (32 output channels, a block of input channels) and walks (image pair, 8x8 region)
+//    items with a double-buffered LDS error tile filled by global_load_lds.  Work is split in chunks
+//    over the items; a small deterministic pass sums the per-chunk partials (no float atomics).
 #include "dau_tiled.hpp"
+
 namespace dau {
-bool tiled_dot_configure(const Shape&, int, int, TiledDotConfig*) { return false; }
-size_t tiled_dot_workspace_bytes(const TiledDotConfig&) { return 0; }
-void tiled_dot_prepare(hipStream_t, const TiledDotConfig&, const float*, const float*, const float*, const UnitRef*, int, int,
-                       void*) {}
-void tiled_dot_run(hipStream_t, const TiledDotConfig&, float*, void*) {}
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* glb_ptr_t;
+
+namespace {
+
+constexpr int kDF = 32;        // output channels per workgroup (half a wave; the two halves are two units g)
+constexpr int kRW = 8, kRH = 8;  // region of positions q handled per item
+constexpr int kDWaves = 16;
+constexpr int kParamDwords = 8;  // per lane per (s, g-pair): b00,b01,b10,b11, base, pad x3
+
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct DotGeometry {
+    int epitch, erows;          // LDS error tile (positions)
+    int rx, ry;                 // regions per image
+    int EX, EY;                 // staged error plane (positions): regions*8 + 2R + 1
+    int Hp, Wp;                 // staged Xk plane (positions): regions*8
+    int GP;                     // unit pairs per (s,f)
+    int AS;                     // input channels per wave
+    int sblock;                 // input channels per workgroup
+    int nfb, nsb, chunks, items;
+    size_t tile_bytes;          // padded to 1 KiB
+};
+
+DotGeometry make_dot_geometry(const Shape& sh, int R) {
+    DotGeometry g{};
+    g.epitch = kRW + 2 * R + 1;
+    g.erows = kRH + 2 * R + 1;
+    g.rx = (sh.W + kRW - 1) / kRW;
+    g.ry = (sh.H + kRH - 1) / kRH;
+    g.EX = g.rx * kRW + 2 * R + 1;
+    g.EY = g.ry * kRH + 2 * R + 1;
+    g.Hp = g.ry * kRH;
+    g.Wp = g.rx * kRW;
+    g.GP = (sh.G + 1) / 2;
+    g.AS = g.GP == 1 ? 4 : (g.GP == 2 ? 2 : 1);
+    g.sblock = kDWaves * g.AS;
+    g.nfb = (sh.F + kDF - 1) / kDF;
+    g.nsb = (sh.S + g.sblock - 1) / g.sblock;
+    g.items = ((sh.N + 1) / 2) * g.rx * g.ry;
+    // enough workgroups to fill the chip several times over, but no more chunks than items
+    int chunks = (256 * 4 + g.nfb * g.nsb - 1) / (g.nfb * g.nsb);
+    if (chunks > g.items) chunks = g.items;
+    if (chunks < 1) chunks = 1;
+    g.chunks = chunks;
+    g.tile_bytes = round_up((size_t)g.erows * g.epitch * kDF * 8, 1024);
+    return g;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// staging kernels
+// ------------------------------------------------------------------------------------------------
+// dy[N,F,H,W] -> EP[NP][nfb][EY][EX][32][2]; padded coordinate Y = y + R + 1, zero elsewhere; the
+// unit_testing edge rule (last column / row of the error dropped) is applied here.
+__global__ void pack_error_kernel(const float* __restrict__ dy, int N, int F, int H, int W, int R, int EX, int EY,
+                                  int nfb, int drop_col, int drop_row, float* __restrict__ ep) {
+    const long total = (long)((N + 1) / 2) * nfb * EY * EX * kDF;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int fl = (int)(idx % kDF);
+        long t = idx / kDF;
+        const int X = (int)(t % EX); t /= EX;
+        const int Y = (int)(t % EY); t /= EY;
+        const int fb = (int)(t % nfb);
+        const int np = (int)(t / nfb);
+        const int y = Y - (R + 1), x = X - (R + 1), f = fb * kDF + fl;
+        float a = 0.0f, b = 0.0f;
+        if (y >= 0 && y < H && x >= 0 && x < W && f < F && !(drop_col && x == W - 1) && !(drop_row && y == H - 1)) {
+            const int n0 = 2 * np, n1 = 2 * np + 1;
+            a = dy[(((long)n0 * F + f) * H + y) * W + x];
+            if (n1 < N) b = dy[(((long)n1 * F + f) * H + y) * W + x];
+        }
+        reinterpret_cast<f2*>(ep)[idx] = f2{a, b};
+    }
+}
+
+// x[N,S,H,W] -> XK[NP][S][Hp][Wp][4][2], the four derivative-filtered copies, zero padded to whole regions.
+__global__ void __launch_bounds__(256) blur4_pack_kernel(const float* __restrict__ in, const float* __restrict__ filt4,
+                                                         int N, int C, int cstride, int H, int W, int k, int Hp,
+                                                         int Wp, float* __restrict__ xk) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int np = blockIdx.x / C, c = blockIdx.x % C;
+    const int kr = (k - 1) / 2;
+    const int lw = W + 2 * kr, lh = H + 2 * kr;
+    for (int t = threadIdx.x; t < lh * lw; t += blockDim.x) {
+        const int yy = t / lw - kr, xx = t % lw - kr;
+        float a = 0.0f, b = 0.0f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const int n0 = 2 * np, n1 = 2 * np + 1;
+            a = in[(((long)n0 * C + c) * H + yy) * W + xx];
+            if (n1 < N) b = in[(((long)n1 * C + c) * H + yy) * W + xx];
+        }
+        lds[2 * t] = a; lds[2 * t + 1] = b;
+    }
+    __syncthreads();
+    f8* out = reinterpret_cast<f8*>(xk) + ((size_t)np * cstride + c) * Hp * Wp;
+    const f2* l2 = reinterpret_cast<const f2*>(lds);
+    for (int t = threadIdx.x; t < Hp * Wp; t += blockDim.x) {
+        const int yy = t / Wp, xx = t % Wp;
+        f2 acc[kNumK];
+#pragma unroll
+        for (int kk = 0; kk < kNumK; ++kk) acc[kk] = f2{0.0f, 0.0f};
+        if (yy < H && xx < W) {
+            for (int j = 0; j < k; ++j)
+                for (int i = 0; i < k; ++i) {
+                    const f2 v = l2[(yy + j) * lw + xx + i];
+#pragma unroll
+                    for (int kk = 0; kk < kNumK; ++kk) {
+                        const float fv = filt4[kk * kFilterPlane + j * k + i];   // wave-uniform -> scalar load
+                        acc[kk].x = fmaf(fv, v.x, acc[kk].x);
+                        acc[kk].y = fmaf(fv, v.y, acc[kk].y);
+                    }
+                }
+        }
+        f8 o;
+#pragma unroll
+        for (int kk = 0; kk < kNumK; ++kk) { o[2 * kk] = acc[kk].x; o[2 * kk + 1] = acc[kk].y; }
+        out[t] = o;
+    }
+}
+
+// per-lane parameters: params[s][gp][fb][lane][8] = {b00, b01, b10, b11, base, 0, 0, 0}
+// lane = half*32 + fl ; unit = (s, g = 2*gp + half, f = fb*32 + fl); invalid units get zero factors.
+__global__ void dot_params_kernel(const UnitRef* __restrict__ table, int S, int G, int F, int R, int epitch, int GP,
+                                  int nfb, int s_pad, float* __restrict__ params) {
+    const long total = (long)s_pad * GP * nfb * 64;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx % 64);
+        long t = idx / 64;
+        const int fb = (int)(t % nfb); t /= nfb;
+        const int gp = (int)(t % GP);
+        const int s = (int)(t / GP);
+        const int g = 2 * gp + (lane >> 5), fl = lane & 31, f = fb * kDF + fl;
+        UnitRef u{0, 0, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (s < S && g < G && f < F) u = table[((long)s * G + g) * F + f];
+        const int base = (((R - u.oy) * epitch + (R - u.ox)) * kDF + fl) * 8;
+        float* dst = params + idx * kParamDwords;
+        dst[0] = u.w00; dst[1] = u.w01; dst[2] = u.w10; dst[3] = u.w11;
+        dst[4] = __int_as_float(base); dst[5] = 0.0f; dst[6] = 0.0f; dst[7] = 0.0f;
+    }
+}
+
+// r4[k][u] = sum over chunks of partial[chunk][k][u]
+__global__ void dot_reduce_kernel(const float* __restrict__ partial, long n, int chunks, float* __restrict__ r4) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int c = 0; c < chunks; ++c) s += (double)partial[(long)c * n + i];
+        r4[i] = (float)s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// main kernel
+// ------------------------------------------------------------------------------------------------
+struct DotArgs {
+    const char* ep;
+    const float* xk;
+    const float* params;
+    float* partial;
+    int N, S, F, G, R;
+    int NP, nfb, nsb, chunks, items;
+    int rx, ry, EX, EY, Hp, Wp, epitch, erows, s_pad;
+    unsigned tile_bytes;
+};
+
+// a * b.x (both halves)            v_pk_mul_f32 with the low half of b broadcast
+__device__ __forceinline__ f2 pk_mul_lo(f2 a, f2 b) {
+    f2 d;
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// a * b.x + c  /  a * b.y + c
+__device__ __forceinline__ f2 pk_fma_lo(f2 a, f2 b, f2 c) {
+    f2 d;
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f2 pk_fma_hi(f2 a, f2 b, f2 c) {
+    f2 d;
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+// a * s + c with s a wave-uniform pair held in SGPRs
+__device__ __forceinline__ f2 pk_fma_s(f2 a, f2 s, f2 c) {
+    f2 d;
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(s), "v"(c));
+    return d;
+}
+
+// LDS reads are inline asm: hipcc would pair them into half-rate ds_read2_b64; waits are placed by hand.
+#define lds_read(dst, addr, imm) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+#define lds_read_imm(dst, addr, imm) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+__device__ __forceinline__ void lgkm_wait0() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);   // keep register-only FMAs below the wait
+}
+
+template <int GP, int AS>
+__global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // workgroup -> (chunk, fb, sb), sb fastest; consecutive logical ids share the error tiles and are
+    // placed on one XCD (blocks b, b+8, ... share an XCD)
+    const int nblk = gridDim.x;
+    int logical;
+    {
+        const int xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+        const int chunk_ = nblk / 8, rem = nblk % 8;
+        logical = (xcd < rem ? xcd * (chunk_ + 1) : rem * (chunk_ + 1) + (xcd - rem) * chunk_) + idx;
+    }
+    const int sb = logical % a.nsb;
+    const int fb = (logical / a.nsb) % a.nfb;
+    const int chunk = logical / (a.nsb * a.nfb);
+
+    // this chunk's contiguous range of items (image pair, region)
+    const int per = (a.items + a.chunks - 1) / a.chunks;
+    const int item0 = chunk * per;
+    const int item1 = item0 + per < a.items ? item0 + per : a.items;
+
+    // per-lane parameters of the wave's AS x GP units, resident in registers for the whole kernel
+    f2 bw[AS][GP][2];
+    unsigned base[AS][GP];
+    int s_of[AS];
+#pragma unroll
+    for (int si = 0; si < AS; ++si) {
+        const int s = sb * (kDWaves * AS) + wave * AS + si;
+        s_of[si] = s;
+#pragma unroll
+        for (int gp = 0; gp < GP; ++gp) {
+            const float* p = a.params + ((((long)s * GP + gp) * a.nfb + fb) * 64 + lane) * kParamDwords;
+            bw[si][gp][0] = f2{p[0], p[1]};
+            bw[si][gp][1] = f2{p[2], p[3]};
+            base[si][gp] = (unsigned)__float_as_int(p[4]);
+        }
+    }
+
+    f2 acc[AS][GP][kNumK];
+#pragma unroll
+    for (int si = 0; si < AS; ++si)
+#pragma unroll
+        for (int gp = 0; gp < GP; ++gp)
+#pragma unroll
+            for (int kk = 0; kk < kNumK; ++kk) acc[si][gp][kk] = f2{0.0f, 0.0f};
+
+    const int regions = a.rx * a.ry;
+    const unsigned tile_bytes = a.tile_bytes;
+    const unsigned row_bytes = (unsigned)a.epitch * kDF * 8;
+
+    auto issue = [&](int item, int buf) {
+        const int np = item / regions, reg = item % regions;
+        const int ry = reg / a.rx, rx = reg % a.rx;
+        const char* src = a.ep + ((((size_t)np * a.nfb + fb) * a.EY + (size_t)ry * kRH) * a.EX + (size_t)rx * kRW) * (kDF * 8);
+        const unsigned pieces = tile_bytes >> 10;
+        for (unsigned piece = wave; piece < pieces; piece += kDWaves) {
+            const unsigned b = piece * 1024 + lane * 16;
+            unsigned trow = b / row_bytes;
+            const unsigned within = b - trow * row_bytes;
+            if (trow >= (unsigned)a.erows) trow = a.erows - 1;        // tail padding: re-read a valid row
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)trow * a.EX * (kDF * 8) + within),
+                                             (lds_ptr_t)(smem + buf * tile_bytes + piece * 1024), 16, 0, 0);
+        }
+    };
+
+    if (item0 < item1) issue(item0, 0);
+    for (int item = item0; item < item1; ++item) {
+        const int buf = (item - item0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (item + 1 < item1) issue(item + 1, buf ^ 1);
+        const int np = item / regions, reg = item % regions;
+        const int ry = reg / a.rx, rx = reg % a.rx;
+        const unsigned bufoff = buf * tile_bytes;
+#pragma unroll
+        for (int si = 0; si < AS; ++si) {
+            // Xk of (pair, s) at the region origin; one position = 8 floats [kind][image]
+            const f8* xrow = reinterpret_cast<const f8*>(a.xk) +
+                             (((size_t)np * a.s_pad + s_of[si]) * a.Hp + (size_t)ry * kRH) * a.Wp + (size_t)rx * kRW;
+            unsigned rowaddr[GP];
+#pragma unroll
+            for (int gp = 0; gp < GP; ++gp) rowaddr[gp] = base[si][gp] + bufoff;
+#pragma unroll 1
+            for (int j = 0; j < kRH; ++j) {
+                // Xk of the row's positions: scalar loads into SGPRs (wave-uniform address), half a row at a time
+                f8 xr[kRW / 2];
+                f2 ep0[GP], ep1[GP], e0n[GP], e1n[GP];
+                unsigned rowaddr2[GP];
+#pragma unroll
+                for (int gp = 0; gp < GP; ++gp) {
+                    rowaddr2[gp] = rowaddr[gp] + row_bytes;
+                    lds_read(ep1[gp], rowaddr[gp], 0);          // tile row j   (dy=1), col 0
+                    lds_read(ep0[gp], rowaddr2[gp], 0);         // tile row j+1 (dy=0), col 0
+                    lds_read(e1n[gp], rowaddr[gp], kDF * 8);
+                    lds_read(e0n[gp], rowaddr2[gp], kDF * 8);
+                }
+#pragma unroll
+                for (int i = 0; i < kRW; ++i) {
+                    if (i % (kRW / 2) == 0) {
+#pragma unroll
+                        for (int h = 0; h < kRW / 2; ++h)
+                            asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(xr[h]) : "s"(xrow), "n"((i + h) * 32) : "memory");
+                    }
+                    lgkm_wait0();                               // column i+1 of both rows (and the Xk half row) landed
+                    f2 e0[GP], e1[GP];
+#pragma unroll
+                    for (int gp = 0; gp < GP; ++gp) { e0[gp] = e0n[gp]; e1[gp] = e1n[gp]; }
+                    if (i + 1 < kRW) {
+#pragma unroll
+                        for (int gp = 0; gp < GP; ++gp) {       // next column, under this position's FMAs
+                            lds_read_imm(e1n[gp], rowaddr[gp], (i + 2) * (kDF * 8));
+                            lds_read_imm(e0n[gp], rowaddr2[gp], (i + 2) * (kDF * 8));
+                        }
+                    }
+                    // Et = b00*E[q-o] + b01*E[q-o-(0,1)] + b10*E[q-o-(1,0)] + b11*E[q-o-(1,1)]
+                    // (the packed ops are volatile asm in exactly this order: the unit pairs are interleaved so
+                    //  that consecutive instructions are independent)
+                    f2 et[GP];
+#pragma unroll
+                    for (int gp = 0; gp < GP; ++gp) et[gp] = pk_mul_lo(e0[gp], bw[si][gp][0]);
+#pragma unroll
+                    for (int gp = 0; gp < GP; ++gp) et[gp] = pk_fma_hi(ep0[gp], bw[si][gp][0], et[gp]);
+#pragma unroll
+                    for (int gp = 0; gp < GP; ++gp) et[gp] = pk_fma_lo(e1[gp], bw[si][gp][1], et[gp]);
+#pragma unroll
+                    for (int gp = 0; gp < GP; ++gp) et[gp] = pk_fma_hi(ep1[gp], bw[si][gp][1], et[gp]);
+#pragma unroll
+                    for (int kk = 0; kk < kNumK; ++kk)
+#pragma unroll
+                        for (int gp = 0; gp < GP; ++gp)
+                            acc[si][gp][kk] = pk_fma_s(et[gp], f2{xr[i % (kRW / 2)][2 * kk], xr[i % (kRW / 2)][2 * kk + 1]}, acc[si][gp][kk]);
+#pragma unroll
+                    for (int gp = 0; gp < GP; ++gp) { ep0[gp] = e0[gp]; ep1[gp] = e1[gp]; }
+                }
+                xrow += a.Wp;
+#pragma unroll
+                for (int gp = 0; gp < GP; ++gp) rowaddr[gp] = rowaddr2[gp];
+            }
+        }
+    }
+
+    // partial[chunk][k][(s*G+g)*F+f] = image 0 + image 1
+    const long units = (long)a.S * a.G * a.F;
+    const int half = lane >> 5, f = fb * kDF + (lane & 31);
+#pragma unroll
+    for (int si = 0; si < AS; ++si)
+#pragma unroll
+        for (int gp = 0; gp < GP; ++gp) {
+            const int s = s_of[si], g = 2 * gp + half;
+            if (s < a.S && g < a.G && f < a.F) {
+                float* dst = a.partial + (long)chunk * kNumK * units + ((long)s * a.G + g) * a.F + f;
+#pragma unroll
+                for (int kk = 0; kk < kNumK; ++kk) dst[kk * units] = acc[si][gp][kk].x + acc[si][gp][kk].y;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct DotLayout {
+    size_t ep_off, xk_off, params_off, partial_off, total;
+};
+
+DotLayout dot_layout(const TiledDotConfig& c, const DotGeometry& g) {
+    DotLayout l{};
+    const size_t NP = (c.sh.N + 1) / 2;
+    const size_t s_pad = (size_t)g.nsb * g.sblock;
+    size_t off = 0;
+    l.ep_off = off; off += round_up(NP * g.nfb * g.EY * g.EX * kDF * 8, 256);
+    l.xk_off = off; off += round_up(NP * s_pad * g.Hp * g.Wp * 32, 256);
+    l.params_off = off; off += round_up(s_pad * g.GP * g.nfb * 64 * kParamDwords * 4, 256);
+    l.partial_off = off; off += round_up((size_t)g.chunks * kNumK * c.sh.S * c.sh.G * c.sh.F * 4, 256);
+    l.total = off;
+    return l;
+}
+
+template <int GP, int AS>
+void launch_dot(hipStream_t st, const DotArgs& a, int grid, size_t lds) {
+    auto kern = gather_dot_kernel<GP, AS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kDWaves * 64), lds, st, a);
+}
+
+}  // namespace
+
+bool tiled_dot_configure(const Shape& sh, int R, int blur_k, TiledDotConfig* cfg) {
+    const DotGeometry g = make_dot_geometry(sh, R);
+    if (g.GP > 3) return false;                                  // G <= 6
+    if (2 * g.tile_bytes > 160 * 1024) return false;             // R = 4 only for now (8x8 regions)
+    // immediates of the unrolled column walk must fit 16 bits
+    if ((size_t)g.epitch * kDF * 8 + (kRW + 1) * kDF * 8 > 65535) return false;
+    const size_t blur_lds = (size_t)(sh.H + blur_k - 1) * (sh.W + blur_k - 1) * 8;
+    if (blur_lds > 64 * 1024) return false;
+    TiledDotConfig c{};
+    c.sh = sh; c.R = R; c.blur_k = blur_k; c.NP = (sh.N + 1) / 2; c.variant = g.GP;
+    *cfg = c;
+    return true;
+}
+
+size_t tiled_dot_workspace_bytes(const TiledDotConfig& c) {
+    return dot_layout(c, make_dot_geometry(c.sh, c.R)).total;
+}
+
+void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, const float* dy, const float* filters4,
+                       const UnitRef* table_bare, int drop_col, int drop_row, void* workspace) {
+    const DotGeometry g = make_dot_geometry(c.sh, c.R);
+    const DotLayout l = dot_layout(c, g);
+    char* ws = static_cast<char*>(workspace);
+    const Shape& s = c.sh;
+    const int s_pad = g.nsb * g.sblock;
+    {
+        const long total = (long)c.NP * g.nfb * g.EY * g.EX * kDF;
+        const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+        hipLaunchKernelGGL(pack_error_kernel, dim3(grid), dim3(256), 0, st, dy, s.N, s.F, s.H, s.W, c.R, g.EX, g.EY, g.nfb,
+                           drop_col, drop_row, reinterpret_cast<float*>(ws + l.ep_off));
+    }
+    {
+        // channels beyond S (padding of the last input-channel block) must read as zero
+        if (s_pad != s.S) (void)hipMemsetAsync(ws + l.xk_off, 0, (size_t)c.NP * s_pad * g.Hp * g.Wp * 32, st);
+        const size_t blur_lds = (size_t)(s.H + c.blur_k - 1) * (s.W + c.blur_k - 1) * 8;
+        // XK is indexed [np][s_pad][Hp][Wp]: launch one block per (np, s) and let the kernel use the padded stride
+        hipLaunchKernelGGL(blur4_pack_kernel, dim3(c.NP * s.S), dim3(256), blur_lds, st, x, filters4, s.N, s.S, s_pad, s.H, s.W,
+                           c.blur_k, g.Hp, g.Wp, reinterpret_cast<float*>(ws + l.xk_off));
+    }
+    {
+        const long total = (long)s_pad * g.GP * g.nfb * 64;
+        const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(dot_params_kernel, dim3(grid), dim3(256), 0, st, table_bare, s.S, s.G, s.F, c.R, g.epitch, g.GP,
+                           g.nfb, s_pad, reinterpret_cast<float*>(ws + l.params_off));
+    }
+}
+
+void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* workspace) {
+    const DotGeometry g = make_dot_geometry(c.sh, c.R);
+    const DotLayout l = dot_layout(c, g);
+    char* ws = static_cast<char*>(workspace);
+    const Shape& s = c.sh;
+    DotArgs a{};
+    a.ep = ws + l.ep_off;
+    a.xk = reinterpret_cast<const float*>(ws + l.xk_off);
+    a.params = reinterpret_cast<const float*>(ws + l.params_off);
+    a.partial = reinterpret_cast<float*>(ws + l.partial_off);
+    a.N = s.N; a.S = s.S; a.F = s.F; a.G = s.G; a.R = c.R;
+    a.NP = c.NP; a.nfb = g.nfb; a.nsb = g.nsb; a.chunks = g.chunks; a.items = g.items;
+    a.rx = g.rx; a.ry = g.ry; a.EX = g.EX; a.EY = g.EY; a.Hp = g.Hp; a.Wp = g.Wp; a.epitch = g.epitch; a.erows = g.erows;
+    a.s_pad = g.nsb * g.sblock;
+    a.tile_bytes = (unsigned)g.tile_bytes;
+    const int grid = g.chunks * g.nfb * g.nsb;
+    const size_t lds = 2 * g.tile_bytes;
+    switch (g.GP) {
+        case 1: launch_dot<1, 4>(st, a, grid, lds); break;
+        case 2: launch_dot<2, 2>(st, a, grid, lds); break;
+        default: launch_dot<3, 1>(st, a, grid, lds); break;
+    }
+    const long n = (long)kNumK * s.S * s.G * s.F;
+    const int rgrid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(dot_reduce_kernel, dim3(rgrid), dim3(256), 0, st, a.partial, n, g.chunks, r4);
+}
+
 }  // namespace dau
