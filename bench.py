@@ -81,15 +81,16 @@ def main():
 
     plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, flags=_capi.FLAG_USE_INTERPOLATION, algo=args.algo,
                       sigma_hint=0.5, mu_learning_rate_factor=1.0)
-    flat = torch.empty(4 * S * G * F, device=dev) if world > 1 else None
+    from dau_conv.distributed import GradBucket
+    bucket = GradBucket((1, S, G, F), dev) if world > 1 else None
 
     def step():
         y = plan.forward(x, w, mu1, mu2, sigma)
         dx, dw, dmu1, dmu2, dsigma = plan.backward(x, dy, w, mu1, mu2, sigma)
         if world > 1:
             # batch-sharded data parallelism: one all-reduce of [dw, dmu1, dmu2, dsigma] over RCCL/xGMI
-            torch.cat([dw.reshape(-1), dmu1.reshape(-1), dmu2.reshape(-1), dsigma.reshape(-1)], out=flat)
-            dist.all_reduce(flat)
+            bucket.pack(dw, dmu1, dmu2, dsigma)
+            bucket.all_reduce()
         return y, dx
 
     def fence():
@@ -134,7 +135,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import dau_oracle as orc
-        ncpu = 2 if N >= 2 else 1
+        ncpu = min(N, 16)
         xs, dys = x[:ncpu].cpu().numpy(), dy[:ncpu].cpu().numpy()
         wn, m1, m2 = w.cpu().numpy(), mu1.cpu().numpy(), mu2.cpu().numpy()
         orc.forward(xs[:1, :4], wn[:, :4], m1[:, :4], m2[:, :4], 0.5)   # load + warm the library
