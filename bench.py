@@ -125,11 +125,22 @@ def main():
             avg = ms / launches
             kern[name] = dict(avg_ms=round(avg, 4), launches=launches, tflops=round(flops[name] / (avg * 1e-3) / 1e12, 2))
     dominant = max(kern, key=lambda n: kern[n]["avg_ms"]) if kern else None
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the number comes
+    # from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/*_pmc_traffic.json)
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["kernels"]
+        key = {"gather_dot": "dau::gather_dot_kernel", "gather_sum_fwd": "dau::gather_mfma_kernel",
+               "gather_sum_dx": "dau::gather_mfma_kernel"}.get(dominant, "")
+        hits = [v["hbm_bytes"] for k, v in pmc.items() if k.startswith(key)] if key and args.workload == "ns" else []
+        traffic = round(hits[0] / 1e9, 3) if hits else None
+    except Exception:
+        traffic = None
     roofline = None
     if dominant:
         ach = flops[dominant] / (kern[dominant]["avg_ms"] * 1e-3) / 1e12
         roofline = dict(bound="mfma", kernel=dominant, achieved=round(ach, 2), peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / FP32_PEAK_TFLOPS, 4), traffic=None, kernels=kern,
+                        frac=round(ach / FP32_PEAK_TFLOPS, 4), traffic=traffic, traffic_unit="GB per launch (2*FETCH_SIZE+WRITE_SIZE)", kernels=kern,
                         whole_step_tflops=round(32.0 * unit_px * args.steps / elapsed / 1e12, 2))
 
     cpu = None

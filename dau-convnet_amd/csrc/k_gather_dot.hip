@@ -23,12 +23,17 @@
 //  * A workgroup owns (32 output channels, a block of input channels) and walks (image pair, 8x8 region)
 //    items with a double-buffered LDS error tile filled by global_load_lds.  Work is split in chunks
 //    over the items; a small deterministic pass sums the per-chunk partials (no float atomics).
+#include <cstdlib>
+#include <type_traits>
+
 #include "dau_tiled.hpp"
 
 namespace dau {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f8 __attribute__((ext_vector_type(8)));
+typedef float f16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* glb_ptr_t;
 
@@ -64,7 +69,7 @@ DotGeometry make_dot_geometry(const Shape& sh, int R) {
     g.Hp = g.ry * kRH;
     g.Wp = g.rx * kRW;
     g.GP = (sh.G + 1) / 2;
-    g.AS = g.GP == 1 ? 4 : (g.GP == 2 ? 2 : 1);
+    g.AS = g.GP == 1 ? 2 : 1;
     g.sblock = kDWaves * g.AS;
     g.nfb = (sh.F + kDF - 1) / kDF;
     g.nsb = (sh.S + g.sblock - 1) / g.sblock;
@@ -193,38 +198,32 @@ struct DotArgs {
     int NP, nfb, nsb, chunks, items;
     int rx, ry, EX, EY, Hp, Wp, epitch, erows, s_pad;
     unsigned tile_bytes;
+    int debug;   // timing experiments only (DAU_DOT_DEBUG): 1 = Xk always from one address, 2 = no error-tile refills
 };
 
-// a * b.x (both halves)            v_pk_mul_f32 with the low half of b broadcast
-__device__ __forceinline__ f2 pk_mul_lo(f2 a, f2 b) {
-    f2 d;
-    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-// a * b.x + c  /  a * b.y + c
-__device__ __forceinline__ f2 pk_fma_lo(f2 a, f2 b, f2 c) {
-    f2 d;
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ f2 pk_fma_hi(f2 a, f2 b, f2 c) {
-    f2 d;
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-// a * s + c with s a wave-uniform pair held in SGPRs
-__device__ __forceinline__ f2 pk_fma_s(f2 a, f2 s, f2 c) {
-    f2 d;
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(s), "v"(c));
-    return d;
-}
+// Packed fp32 helpers.  Plain vector builtins (not inline asm): hipcc selects v_pk_mul_f32 / v_pk_fma_f32,
+// folds the broadcast of a bilinear factor into op_sel (or a loop-invariant register pair) and takes the
+// wave-uniform Xk pair straight from SGPRs.  Inline-asm versions cost an s_nop per dependent pair because
+// the hazard recognizer must assume the worst about asm results.
+__device__ __forceinline__ f2 pk_mul_lo(f2 a, f2 b) { return a * f2{b.x, b.x}; }
+__device__ __forceinline__ f2 pk_fma_lo(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, f2{b.x, b.x}, c); }
+__device__ __forceinline__ f2 pk_fma_hi(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, f2{b.y, b.y}, c); }
+__device__ __forceinline__ f2 pk_fma_s(f2 a, f2 s, f2 c) { return __builtin_elementwise_fma(a, s, c); }
 
 // LDS reads are inline asm: hipcc would pair them into half-rate ds_read2_b64; waits are placed by hand.
 #define lds_read(dst, addr, imm) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
 #define lds_read_imm(dst, addr, imm) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
+// Xk ring: the destination is a read-write operand so that the register stays put across loop back-edges.
+#define x_load(dst, voff, sbase, imm) asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "+v"(dst) : "v"(voff), "s"(sbase), "n"(imm) : "memory")
+__device__ __forceinline__ void x_wait7() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
 __device__ __forceinline__ void lgkm_wait0() {
+    __builtin_amdgcn_sched_barrier(0);   // the previous position's FMAs stay above the wait (they cover the reads in flight)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);   // keep register-only FMAs below the wait
+    __builtin_amdgcn_sched_barrier(0);   // and this position's FMAs stay below it
 }
 
 template <int GP, int AS>
@@ -268,13 +267,11 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
         }
     }
 
-    f2 acc[AS][GP][kNumK];
+    f4 acc[AS][GP][2];   // [input channel][unit pair][image]: register k = gradient kind
 #pragma unroll
     for (int si = 0; si < AS; ++si)
 #pragma unroll
-        for (int gp = 0; gp < GP; ++gp)
-#pragma unroll
-            for (int kk = 0; kk < kNumK; ++kk) acc[si][gp][kk] = f2{0.0f, 0.0f};
+        for (int gp = 0; gp < GP; ++gp) { acc[si][gp][0] = f4{0, 0, 0, 0}; acc[si][gp][1] = f4{0, 0, 0, 0}; }
 
     const int regions = a.rx * a.ry;
     const unsigned tile_bytes = a.tile_bytes;
@@ -295,81 +292,146 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
         }
     };
 
-    if (item0 < item1) issue(item0, 0);
+    // Xk of (item, s) at the region origin; one position = 8 floats [kind][image].  Lane l fetches the image
+    // pair of kind l%4: exactly the A operand of v_mfma_f32_4x4x1 (lane 4b+i supplies A[i]).  The address is a
+    // wave-uniform base (SGPR pair) + the per-lane kind offset (one VGPR) + an immediate: no address VALU.
+    const size_t xpitch = (size_t)a.Wp * 32;
+    const unsigned xlane = (lane & 3) * 8;
+    auto sweep_ptr = [&](int item, int s) -> const char* {
+        const int np_ = item / regions, reg_ = item % regions;
+        const int ry_ = reg_ / a.rx, rx_ = reg_ % a.rx;
+        return reinterpret_cast<const char*>(a.xk) +
+               ((((size_t)np_ * a.s_pad + s) * a.Hp + (size_t)ry_ * kRH) * a.Wp + (size_t)rx_ * kRW) * 32;
+    };
+    // Ring of the next 8 positions' Xk (2 VGPRs each), filled by ordinary vector loads and retired with
+    // COUNTED vmcnt waits: vector memory returns in order and is independent of the LDS counter.  The ring
+    // runs continuously across sweeps and items (the last row of a sweep refills it with the first row of
+    // the next sweep), so the memory latency is exposed once per kernel, not once per item.
+    // (The first version fetched Xk with scalar loads: they share lgkmcnt with LDS and return out of order, so
+    //  every LDS wait had to drain them; measured 6 ms of exposed scalar-miss latency.)
+    f2 xr[kRW];
+#pragma unroll
+    for (int i = 0; i < kRW; ++i) xr[i] = f2{0.0f, 0.0f};
+    if (item0 < item1) {
+        issue(item0, 0);
+        const char* x0 = sweep_ptr(item0, s_of[0]);
+#pragma unroll
+        for (int i = 0; i < kRW; ++i) x_load(xr[i], xlane, x0, i * 32);
+    }
     for (int item = item0; item < item1; ++item) {
         const int buf = (item - item0) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // the error tile of this item was requested one whole item ago: everything but the 8 newest vector
+        // memory operations (the Xk ring) has to be complete
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __syncthreads();
-        if (item + 1 < item1) issue(item + 1, buf ^ 1);
-        const int np = item / regions, reg = item % regions;
-        const int ry = reg / a.rx, rx = reg % a.rx;
+        if (item + 1 < item1 && !(a.debug & 2)) issue(item + 1, buf ^ 1);
         const unsigned bufoff = buf * tile_bytes;
 #pragma unroll
         for (int si = 0; si < AS; ++si) {
-            // Xk of (pair, s) at the region origin; one position = 8 floats [kind][image]
-            const f8* xrow = reinterpret_cast<const f8*>(a.xk) +
-                             (((size_t)np * a.s_pad + s_of[si]) * a.Hp + (size_t)ry * kRH) * a.Wp + (size_t)rx * kRW;
-            unsigned rowaddr[GP];
+            const char* xbase = sweep_ptr(item, s_of[si]);
+            // where the ring continues after this sweep: next input channel of this item, or the next item
+            // (or, at the very end, the last row again so that the number of loads in flight stays constant)
+            const char* xnext_sweep = si + 1 < AS ? sweep_ptr(item, s_of[si + 1 < AS ? si + 1 : si])
+                                                  : (item + 1 < item1 ? sweep_ptr(item + 1, s_of[0]) : xbase + (kRH - 1) * xpitch);
+
+            // The sweep over the 8x8 region is fully unrolled (no back-edge copies).  Software pipeline over groups
+            // of two positions: at the END of a group one lgkmcnt(0) retires the error columns prefetched for the
+            // next group, which flew under this group's work.
+            f2 eb[2][GP][2][2];          // [buffer parity][unit pair][row: 0 = tile row j (dy=1), 1 = row j+1 (dy=0)][col]
+            f2 epn[GP][2];               // column 0 of a row (precedes its first group)
+            f2 etp = f2{0.0f, 0.0f};     // interpolated error whose two MFMAs are pending
+            unsigned rowaddr[GP], rowaddr2[GP];
 #pragma unroll
-            for (int gp = 0; gp < GP; ++gp) rowaddr[gp] = base[si][gp] + bufoff;
-#pragma unroll 1
-            for (int j = 0; j < kRH; ++j) {
-                // Xk of the row's positions: scalar loads into SGPRs (wave-uniform address), half a row at a time
-                f8 xr[kRW / 2];
-                f2 ep0[GP], ep1[GP], e0n[GP], e1n[GP];
-                unsigned rowaddr2[GP];
-#pragma unroll
-                for (int gp = 0; gp < GP; ++gp) {
-                    rowaddr2[gp] = rowaddr[gp] + row_bytes;
-                    lds_read(ep1[gp], rowaddr[gp], 0);          // tile row j   (dy=1), col 0
-                    lds_read(ep0[gp], rowaddr2[gp], 0);         // tile row j+1 (dy=0), col 0
-                    lds_read(e1n[gp], rowaddr[gp], kDF * 8);
-                    lds_read(e0n[gp], rowaddr2[gp], kDF * 8);
-                }
-#pragma unroll
-                for (int i = 0; i < kRW; ++i) {
-                    if (i % (kRW / 2) == 0) {
-#pragma unroll
-                        for (int h = 0; h < kRW / 2; ++h)
-                            asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(xr[h]) : "s"(xrow), "n"((i + h) * 32) : "memory");
-                    }
-                    lgkm_wait0();                               // column i+1 of both rows (and the Xk half row) landed
-                    f2 e0[GP], e1[GP];
-#pragma unroll
-                    for (int gp = 0; gp < GP; ++gp) { e0[gp] = e0n[gp]; e1[gp] = e1n[gp]; }
-                    if (i + 1 < kRW) {
-#pragma unroll
-                        for (int gp = 0; gp < GP; ++gp) {       // next column, under this position's FMAs
-                            lds_read_imm(e1n[gp], rowaddr[gp], (i + 2) * (kDF * 8));
-                            lds_read_imm(e0n[gp], rowaddr2[gp], (i + 2) * (kDF * 8));
-                        }
-                    }
-                    // Et = b00*E[q-o] + b01*E[q-o-(0,1)] + b10*E[q-o-(1,0)] + b11*E[q-o-(1,1)]
-                    // (the packed ops are volatile asm in exactly this order: the unit pairs are interleaved so
-                    //  that consecutive instructions are independent)
-                    f2 et[GP];
-#pragma unroll
-                    for (int gp = 0; gp < GP; ++gp) et[gp] = pk_mul_lo(e0[gp], bw[si][gp][0]);
-#pragma unroll
-                    for (int gp = 0; gp < GP; ++gp) et[gp] = pk_fma_hi(ep0[gp], bw[si][gp][0], et[gp]);
-#pragma unroll
-                    for (int gp = 0; gp < GP; ++gp) et[gp] = pk_fma_lo(e1[gp], bw[si][gp][1], et[gp]);
-#pragma unroll
-                    for (int gp = 0; gp < GP; ++gp) et[gp] = pk_fma_hi(ep1[gp], bw[si][gp][1], et[gp]);
-#pragma unroll
-                    for (int kk = 0; kk < kNumK; ++kk)
-#pragma unroll
-                        for (int gp = 0; gp < GP; ++gp)
-                            acc[si][gp][kk] = pk_fma_s(et[gp], f2{xr[i % (kRW / 2)][2 * kk], xr[i % (kRW / 2)][2 * kk + 1]}, acc[si][gp][kk]);
-#pragma unroll
-                    for (int gp = 0; gp < GP; ++gp) { ep0[gp] = e0[gp]; ep1[gp] = e1[gp]; }
-                }
-                xrow += a.Wp;
-#pragma unroll
-                for (int gp = 0; gp < GP; ++gp) rowaddr[gp] = rowaddr2[gp];
+            for (int gp = 0; gp < GP; ++gp) {
+                rowaddr[gp] = base[si][gp] + bufoff;
+                rowaddr2[gp] = rowaddr[gp] + row_bytes;
+                lds_read(epn[gp][0], rowaddr[gp], 0);
+                lds_read(epn[gp][1], rowaddr2[gp], 0);
+                lds_read(eb[0][gp][0][0], rowaddr[gp], 1 * (kDF * 8));
+                lds_read(eb[0][gp][1][0], rowaddr2[gp], 1 * (kDF * 8));
+                lds_read(eb[0][gp][0][1], rowaddr[gp], 2 * (kDF * 8));
+                lds_read(eb[0][gp][1][1], rowaddr2[gp], 2 * (kDF * 8));
             }
+            lgkm_wait0();
+#pragma unroll
+            for (int j = 0; j < kRH; ++j) {
+                const char* xcur = xbase + j * xpitch;                                        // Xk row being consumed
+                const char* xreload = j + 1 < kRH ? xbase + (j + 1) * xpitch : xnext_sweep;   // row refilling the ring
+#pragma unroll
+                for (int gq = 0; gq < kRW / 2; ++gq) {
+                    constexpr int kGroups = kRW / 2;
+                    const int par = gq & 1;
+                    // Prefetch the following group's error columns into the other buffer.  That buffer's SECOND column is still
+                    // needed (as the left neighbour) by this group's first position, so only the first column is requested
+                    // now; the second follows after position 0 (prefetch_col<1> below).
+#define DAU_PREFETCH_COL(col)                                                                                       \
+    if (gq + 1 < kGroups) {                                                                                         \
+        _Pragma("unroll") for (int gp = 0; gp < GP; ++gp) {                                                         \
+            lds_read(eb[par ^ 1][gp][0][col], rowaddr[gp], (2 * gq + 3 + col) * (kDF * 8));                         \
+            lds_read(eb[par ^ 1][gp][1][col], rowaddr2[gp], (2 * gq + 3 + col) * (kDF * 8));                        \
+        }                                                                                                           \
+    } else if (j + 1 < kRH) {                                                                                       \
+        /* first group of the next row: tile rows j+1 and j+2 (rowaddr2 / rowaddr2 + pitch), columns 0..2 */        \
+        _Pragma("unroll") for (int gp = 0; gp < GP; ++gp) {                                                         \
+            const unsigned r3 = rowaddr2[gp] + row_bytes;                                                           \
+            if (col == 0) {                                                                                         \
+                lds_read(epn[gp][0], rowaddr2[gp], 0);                                                              \
+                lds_read(epn[gp][1], r3, 0);                                                                        \
+            }                                                                                                       \
+            lds_read(eb[par ^ 1][gp][0][col], rowaddr2[gp], (1 + col) * (kDF * 8));                                 \
+            lds_read(eb[par ^ 1][gp][1][col], r3, (1 + col) * (kDF * 8));                                           \
+        }                                                                                                           \
+    }
+                    DAU_PREFETCH_COL(0)
+                    // the group's two positions; element order (p0,g0) (p0,g1) (p1,g0) (p1,g1): the MFMAs of an element
+                    // are issued after the interpolation block of the next one
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const int i = 2 * gq + p;                  // position in the row
+                        const int iprev = (i + kRW - 1) % kRW;     // position of the pending element when gp == 0
+#pragma unroll
+                        for (int gp = 0; gp < GP; ++gp) {
+                            const f2 e1 = eb[par][gp][0][p], e0 = eb[par][gp][1][p];
+                            // column to the left: the row's column 0, the previous group's second column, or this group's first
+                            const f2 l1 = p == 1 ? eb[par][gp][0][0] : (gq == 0 ? epn[gp][0] : eb[par ^ 1][gp][0][1]);
+                            const f2 l0 = p == 1 ? eb[par][gp][1][0] : (gq == 0 ? epn[gp][1] : eb[par ^ 1][gp][1][1]);
+                            // Et = b00*E[q-o] + b01*E[q-o-(0,1)] + b10*E[q-o-(1,0)] + b11*E[q-o-(1,1)]; every dependency is
+                            // through the accumulator operand, which needs no wait state
+                            f2 et;
+                            asm volatile("v_pk_mul_f32 %0, %1, %5 op_sel_hi:[1,0]\n\t"
+                                         "v_pk_fma_f32 %0, %2, %5, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                                         "v_pk_fma_f32 %0, %3, %6, %0 op_sel_hi:[1,0,1]\n\t"
+                                         "v_pk_fma_f32 %0, %4, %6, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+                                         : "=&v"(et)
+                                         : "v"(e0), "v"(l0), "v"(e1), "v"(l1), "v"(bw[si][gp][0]), "v"(bw[si][gp][1]));
+                            __builtin_amdgcn_sched_barrier(0);
+                            // pending element: kinds x its interpolated error, one MFMA per image
+                            const int pi = gp == 0 ? iprev : i, pg = gp == 0 ? GP - 1 : gp - 1;
+                            if (gp == (GP > 1 ? 1 : 0)) x_wait7();     // first use of xr[i] (GP>1) / xr[iprev] (GP==1)
+                            acc[si][pg][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xr[pi].x, etp.x, acc[si][pg][0], 0, 0, 0);
+                            acc[si][pg][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xr[pi].y, etp.y, acc[si][pg][1], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            // position iprev fully consumed: refill its ring slot (at i == 0 it belongs to the row just begun)
+                            if (gp == 0) x_load(xr[iprev], xlane, i == 0 ? xcur : xreload, iprev * 32);
+                            etp = et;
+                        }
+                        if (p == 0) { DAU_PREFETCH_COL(1) }
+                    }
+                    lgkm_wait0();   // the prefetched group has landed
+                }
+                // next row: tile rows shift down by one
+#pragma unroll
+                for (int gp = 0; gp < GP; ++gp) { rowaddr[gp] = rowaddr2[gp]; rowaddr2[gp] += row_bytes; }
+            }
+            // drain: the sweep's last element (position kRW-1 of the last row), then hand its ring slot on
+            x_wait7();
+            acc[si][GP - 1][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xr[kRW - 1].x, etp.x, acc[si][GP - 1][0], 0, 0, 0);
+            acc[si][GP - 1][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xr[kRW - 1].y, etp.y, acc[si][GP - 1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            x_load(xr[kRW - 1], xlane, xnext_sweep, (kRW - 1) * 32);
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // partial[chunk][k][(s*G+g)*F+f] = image 0 + image 1
     const long units = (long)a.S * a.G * a.F;
@@ -382,7 +444,7 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
             if (s < a.S && g < a.G && f < a.F) {
                 float* dst = a.partial + (long)chunk * kNumK * units + ((long)s * a.G + g) * a.F + f;
 #pragma unroll
-                for (int kk = 0; kk < kNumK; ++kk) dst[kk * units] = acc[si][gp][kk].x + acc[si][gp][kk].y;
+                for (int kk = 0; kk < kNumK; ++kk) dst[kk * units] = acc[si][gp][0][kk] + acc[si][gp][1][kk];
             }
         }
 }
@@ -424,7 +486,7 @@ void launch_dot(hipStream_t st, const DotArgs& a, int grid, size_t lds) {
 
 bool tiled_dot_configure(const Shape& sh, int R, int blur_k, TiledDotConfig* cfg) {
     const DotGeometry g = make_dot_geometry(sh, R);
-    if (g.GP > 3) return false;                                  // G <= 6
+    if (g.GP > 2) return false;                                  // G <= 4 (three unit pairs per wave spill registers)
     if (2 * g.tile_bytes > 160 * 1024) return false;             // R = 4 only for now (8x8 regions)
     // immediates of the unrolled column walk must fit 16 bits
     if ((size_t)g.epitch * kDF * 8 + (kRW + 1) * kDF * 8 > 65535) return false;
@@ -484,12 +546,13 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
     a.rx = g.rx; a.ry = g.ry; a.EX = g.EX; a.EY = g.EY; a.Hp = g.Hp; a.Wp = g.Wp; a.epitch = g.epitch; a.erows = g.erows;
     a.s_pad = g.nsb * g.sblock;
     a.tile_bytes = (unsigned)g.tile_bytes;
+    a.debug = getenv("DAU_DOT_DEBUG") ? atoi(getenv("DAU_DOT_DEBUG")) : 0;
     const int grid = g.chunks * g.nfb * g.nsb;
     const size_t lds = 2 * g.tile_bytes;
     switch (g.GP) {
-        case 1: launch_dot<1, 4>(st, a, grid, lds); break;
-        case 2: launch_dot<2, 2>(st, a, grid, lds); break;
-        default: launch_dot<3, 1>(st, a, grid, lds); break;
+        case 1: launch_dot<1, 2>(st, a, grid, lds); break;
+        case 2: launch_dot<2, 1>(st, a, grid, lds); break;
+        default: break;
     }
     const long n = (long)kNumK * s.S * s.G * s.F;
     const int rgrid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);

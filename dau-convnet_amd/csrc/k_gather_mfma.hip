@@ -22,6 +22,7 @@
 //  * A workgroup owns (image pair, FB output channels) and streams all input channels through a
 //    double-buffered LDS plane filled by global_load_lds (no VGPR staging) from a pre-blurred,
 //    zero-bordered, pair-interleaved copy written by blur_pack_kernel.
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -145,6 +146,7 @@ struct GatherArgs {
     int nfb;                   // ceil(Cout / kFB)
     unsigned plane_bytes, ut_stride;
     unsigned zpitch;           // epilogue Z-plane pitch (floats)
+    int debug;                 // timing experiments only (DAU_GATHER_DEBUG): 1 = no plane refills after the first two
 };
 
 // TX, TY : regular 8x8 tiles;  PITCH: staged pitch (positions);  EDGE: two extra edge tiles
@@ -295,7 +297,7 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
         const int buf = c & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // plane c is in LDS for everyone; everyone is done reading plane c-1
-        if (c + 1 < a.Cin) issue(c + 1, buf ^ 1);
+        if (c + 1 < a.Cin && !((a.debug & 1) && c >= 1)) issue(c + 1, buf ^ 1);
         const unsigned pbase = buf * plane_bytes;
         const char* ut = smem + ut_base + buf * ut_stride + (fi * kUnitDwords + (lane & 3) * 2) * 4;
         const unsigned ut_addr = (unsigned)(ut - smem);
@@ -381,6 +383,7 @@ const Variant kVariants[] = {
     {3, 3, 40, 1, 1},    // 24x24
     {1, 1, 40, 1, 1},    // 8x8
     {4, 4, 40, 0, 1},    // 25..31 square-ish (27x27, 28x28), R=4
+    {7, 7, 72, 1, 3},    // 56x56, R=4, three waves per output channel (tuning alternative, DAU_GATHER_SPLIT=3)
 };
 
 template <int TX, int TY, int PITCH, bool EDGE, int SPLIT>
@@ -409,10 +412,13 @@ size_t lds_bytes(const TiledConfig& c, const Geometry& g) {
 bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, TiledConfig* cfg) {
     const Geometry g = make_geometry(H, W, R);
     int variant = -1;
+    const char* split_env = getenv("DAU_GATHER_SPLIT");      // tuning knob: waves per output channel
+    const int want_split = split_env ? atoi(split_env) : 0;
     for (size_t i = 0; i < sizeof(kVariants) / sizeof(kVariants[0]); ++i)
-        if (kVariants[i].tx == g.tx && kVariants[i].ty == g.ty && kVariants[i].pitch == g.pitch && kVariants[i].edge == g.edge) {
-            variant = (int)i;
-            break;
+        if (kVariants[i].tx == g.tx && kVariants[i].ty == g.ty && kVariants[i].pitch == g.pitch && kVariants[i].edge == g.edge &&
+            (want_split == 0 || kVariants[i].split == want_split || variant < 0)) {
+            if (variant < 0 || kVariants[i].split == want_split) variant = (int)i;
+            if (want_split == 0) break;
         }
     if (variant < 0) return false;
     TiledConfig c{};
@@ -462,6 +468,7 @@ void tiled_gather_run(hipStream_t st, const TiledConfig& c, float* out, void* wo
     a.plane_bytes = (unsigned)g.plane_bytes;
     a.ut_stride = (unsigned)ut_stride_bytes(c.G);
     a.zpitch = (unsigned)(c.W + 2);
+    a.debug = getenv("DAU_GATHER_DEBUG") ? atoi(getenv("DAU_GATHER_DEBUG")) : 0;
     const int grid = c.NP * a.nfb;
     const size_t lds = lds_bytes(c, g);
     switch (c.variant) {
@@ -472,6 +479,7 @@ void tiled_gather_run(hipStream_t st, const TiledConfig& c, float* out, void* wo
         case 4: launch_variant<3, 3, 40, true, 1>(st, a, grid, lds); break;
         case 5: launch_variant<1, 1, 40, true, 1>(st, a, grid, lds); break;
         case 6: launch_variant<4, 4, 40, false, 1>(st, a, grid, lds); break;
+        case 7: launch_variant<7, 7, 72, true, 3>(st, a, grid, lds); break;
         default: break;
     }
 }
