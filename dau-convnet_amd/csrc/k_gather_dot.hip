@@ -69,7 +69,7 @@ DotGeometry make_dot_geometry(const Shape& sh, int R) {
     g.Hp = g.ry * kRH;
     g.Wp = g.rx * kRW;
     g.GP = (sh.G + 1) / 2;
-    g.AS = g.GP == 1 ? 2 : 1;
+    g.AS = (getenv("DAU_DOT_AS1") && g.GP == 2) ? 1 : 2;
     g.sblock = kDWaves * g.AS;
     g.nfb = (sh.F + kDF - 1) / kDF;
     g.nsb = (sh.S + g.sblock - 1) / g.sblock;
@@ -215,9 +215,10 @@ __device__ __forceinline__ f2 pk_fma_s(f2 a, f2 s, f2 c) { return __builtin_elem
 #define lds_read_imm(dst, addr, imm) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
 // Xk ring: the destination is a read-write operand so that the register stays put across loop back-edges.
 #define x_load(dst, voff, sbase, imm) asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "+v"(dst) : "v"(voff), "s"(sbase), "n"(imm) : "memory")
-__device__ __forceinline__ void x_wait7() {
+// ring of 8 loads: the two oldest are complete when at most 6 are outstanding
+__device__ __forceinline__ void x_wait6() {
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
 __device__ __forceinline__ void lgkm_wait0() {
@@ -339,7 +340,6 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
             // next group, which flew under this group's work.
             f2 eb[2][GP][2][2];          // [buffer parity][unit pair][row: 0 = tile row j (dy=1), 1 = row j+1 (dy=0)][col]
             f2 epn[GP][2];               // column 0 of a row (precedes its first group)
-            f2 etp = f2{0.0f, 0.0f};     // interpolated error whose two MFMAs are pending
             unsigned rowaddr[GP], rowaddr2[GP];
 #pragma unroll
             for (int gp = 0; gp < GP; ++gp) {
@@ -355,7 +355,6 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
             lgkm_wait0();
 #pragma unroll
             for (int j = 0; j < kRH; ++j) {
-                const char* xcur = xbase + j * xpitch;                                        // Xk row being consumed
                 const char* xreload = j + 1 < kRH ? xbase + (j + 1) * xpitch : xnext_sweep;   // row refilling the ring
 #pragma unroll
                 for (int gq = 0; gq < kRW / 2; ++gq) {
@@ -383,12 +382,12 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
         }                                                                                                           \
     }
                     DAU_PREFETCH_COL(0)
-                    // the group's two positions; element order (p0,g0) (p0,g1) (p1,g0) (p1,g1): the MFMAs of an element
-                    // are issued after the interpolation block of the next one
+                    // The group's two positions x GP unit pairs = 2*GP elements: first ALL interpolation blocks (8*GP packed
+                    // ops), then ALL kind-contractions (4*GP MFMAs).  Alternating the packed-VALU and MFMA pipes in small
+                    // groups is slow on gfx950 (tools/microbench/mfma_pk_grouping: 2 MFMA + 4 pk per switch 125 TF, 8 + 16: 143 TF).
+                    f2 et[2][GP];
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
-                        const int i = 2 * gq + p;                  // position in the row
-                        const int iprev = (i + kRW - 1) % kRW;     // position of the pending element when gp == 0
 #pragma unroll
                         for (int gp = 0; gp < GP; ++gp) {
                             const f2 e1 = eb[par][gp][0][p], e0 = eb[par][gp][1][p];
@@ -397,38 +396,36 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
                             const f2 l0 = p == 1 ? eb[par][gp][1][0] : (gq == 0 ? epn[gp][1] : eb[par ^ 1][gp][1][1]);
                             // Et = b00*E[q-o] + b01*E[q-o-(0,1)] + b10*E[q-o-(1,0)] + b11*E[q-o-(1,1)]; every dependency is
                             // through the accumulator operand, which needs no wait state
-                            f2 et;
                             asm volatile("v_pk_mul_f32 %0, %1, %5 op_sel_hi:[1,0]\n\t"
                                          "v_pk_fma_f32 %0, %2, %5, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
                                          "v_pk_fma_f32 %0, %3, %6, %0 op_sel_hi:[1,0,1]\n\t"
                                          "v_pk_fma_f32 %0, %4, %6, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
-                                         : "=&v"(et)
+                                         : "=&v"(et[p][gp])
                                          : "v"(e0), "v"(l0), "v"(e1), "v"(l1), "v"(bw[si][gp][0]), "v"(bw[si][gp][1]));
-                            __builtin_amdgcn_sched_barrier(0);
-                            // pending element: kinds x its interpolated error, one MFMA per image
-                            const int pi = gp == 0 ? iprev : i, pg = gp == 0 ? GP - 1 : gp - 1;
-                            if (gp == (GP > 1 ? 1 : 0)) x_wait7();     // first use of xr[i] (GP>1) / xr[iprev] (GP==1)
-                            acc[si][pg][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xr[pi].x, etp.x, acc[si][pg][0], 0, 0, 0);
-                            acc[si][pg][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xr[pi].y, etp.y, acc[si][pg][1], 0, 0, 0);
-                            __builtin_amdgcn_sched_barrier(0);
-                            // position iprev fully consumed: refill its ring slot (at i == 0 it belongs to the row just begun)
-                            if (gp == 0) x_load(xr[iprev], xlane, i == 0 ? xcur : xreload, iprev * 32);
-                            etp = et;
                         }
-                        if (p == 0) { DAU_PREFETCH_COL(1) }
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // the other buffer's second column (left neighbour of this group's first position) is now consumed
+                    { DAU_PREFETCH_COL(1) }
+                    x_wait6();      // Xk of both positions of the group
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                        for (int gp = 0; gp < GP; ++gp) {
+                            acc[si][gp][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xr[2 * gq + p].x, et[p][gp].x, acc[si][gp][0], 0, 0, 0);
+                            acc[si][gp][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xr[2 * gq + p].y, et[p][gp].y, acc[si][gp][1], 0, 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // both ring slots are consumed: refill them with the next row (or the next sweep's first row)
+                    x_load(xr[2 * gq], xlane, xreload, (2 * gq) * 32);
+                    x_load(xr[2 * gq + 1], xlane, xreload, (2 * gq + 1) * 32);
                     lgkm_wait0();   // the prefetched group has landed
                 }
                 // next row: tile rows shift down by one
 #pragma unroll
                 for (int gp = 0; gp < GP; ++gp) { rowaddr[gp] = rowaddr2[gp]; rowaddr2[gp] += row_bytes; }
             }
-            // drain: the sweep's last element (position kRW-1 of the last row), then hand its ring slot on
-            x_wait7();
-            acc[si][GP - 1][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xr[kRW - 1].x, etp.x, acc[si][GP - 1][0], 0, 0, 0);
-            acc[si][GP - 1][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xr[kRW - 1].y, etp.y, acc[si][GP - 1][1], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            x_load(xr[kRW - 1], xlane, xnext_sweep, (kRW - 1) * 32);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -551,7 +548,7 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
     const size_t lds = 2 * g.tile_bytes;
     switch (g.GP) {
         case 1: launch_dot<1, 2>(st, a, grid, lds); break;
-        case 2: launch_dot<2, 1>(st, a, grid, lds); break;
+        case 2: if (g.AS == 2) launch_dot<2, 2>(st, a, grid, lds); else launch_dot<2, 1>(st, a, grid, lds); break;
         default: break;
     }
     const long n = (long)kNumK * s.S * s.G * s.F;

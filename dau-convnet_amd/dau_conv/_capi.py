@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libdau_conv_hip.so")
+# DAU_CONV_LIB selects another build of the same ABI (A/B timing of kernel variants on one device)
+_LIB_PATH = os.environ.get("DAU_CONV_LIB") or os.path.join(_HERE, "libdau_conv_hip.so")
 
 DAU_OK, DAU_INVALID_ARGUMENT, DAU_FAILED_PRECONDITION, DAU_INTERNAL = 0, 1, 2, 3
 
