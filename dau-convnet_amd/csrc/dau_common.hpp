@@ -10,6 +10,13 @@ namespace dau {
 constexpr int kMaxBlurSupport = 17;                       // convolve.cu:40 caps the prefilter at 17x17
 constexpr int kFilterPlane = kMaxBlurSupport * kMaxBlurSupport;
 constexpr int kNumK = 4;                                  // gradient kinds {w, mu1, mu2, sigma}
+// The prefilters are separable: Gn = gx (x) gy, Dmu1 = ax (x) gy, Dmu2 = gx (x) ay, Dsigma = cx (x) gy + gx (x) by
+// (SURVEY.md Appendix A item 1 rewritten with 1-D factors).  synth_filters_kernel also emits these taps, after
+// the six 2-D planes: eight arrays of kTapPitch floats.
+constexpr int kTapPitch = 32;
+enum Tap1d { kTapGX = 0, kTapGY, kTapAX, kTapAY, kTapCX, kTapBY, kTapGXR, kTapGYR, kNumTap1d };
+constexpr int kTaps1dOffset = 6 * kFilterPlane;
+constexpr int kFilterFloats = kTaps1dOffset + kNumTap1d * kTapPitch;
 
 // Device-side status block at the head of every workspace (see dau_conv_check_status).
 struct Status {

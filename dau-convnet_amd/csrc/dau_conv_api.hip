@@ -120,7 +120,7 @@ FwdWs carve_forward(const dau_conv_plan* p, void* ws) {
     Carver c(ws);
     FwdWs w{};
     w.status = c.take<Status>(1);
-    w.filters = c.take<float>(6 * kFilterPlane);
+    w.filters = c.take<float>(kFilterFloats);
     w.table = c.take<UnitRef>(p->units());
     if (p->algo_fwd == DAU_ALGO_TILED) {
         w.tiled = c.take<char>(tiled_gather_workspace_bytes(p->tiled_fwd));
@@ -149,7 +149,7 @@ BwdWs carve_backward(const dau_conv_plan* p, void* ws) {
     BwdWs w{};
     const Shape& s = p->sh;
     w.status = c.take<Status>(1);
-    w.filters = c.take<float>(6 * kFilterPlane);
+    w.filters = c.take<float>(kFilterFloats);
     w.table_bare = c.take<UnitRef>(p->units());
     w.table_t = c.take<UnitRef>(p->units());
     w.r4 = c.take<float>(kNumK * p->units());
@@ -293,7 +293,7 @@ int dau_conv_forward(const dau_conv_plan* p, void* stream, const float* x, const
     launch_synth_filters(st, sigma, p->blur_k, p->d.flags, ws.filters);
     launch_prepare_units(st, w, mu1, mu2, s, p->d.number_units_ignore, p->d.flags, p->bucket, false, ws.table, ws.status);
     if (p->algo_fwd == DAU_ALGO_TILED) {
-        tiled_gather_prepare(st, p->tiled_fwd, x, ws.filters + 0 * kFilterPlane, ws.table, ws.tiled);
+        tiled_gather_prepare(st, p->tiled_fwd, x, ws.filters, false, ws.table, ws.tiled);
         ProfScope prof(p, 0, st);
         tiled_gather_run(st, p->tiled_fwd, y, ws.tiled);
     } else {
@@ -328,7 +328,7 @@ int dau_conv_backward(const dau_conv_plan* p, void* stream, const float* x, cons
         launch_prepare_units(st, nullptr, mu1, mu2, s, p->d.number_units_ignore, flags, p->bucket, false, ws.table_bare,
                              ws.status);
         if (p->algo_bwd == DAU_ALGO_TILED) {
-            tiled_dot_prepare(st, p->tiled_dot, x, dy, ws.filters + 1 * kFilterPlane, ws.table_bare, p->drop_col,
+            tiled_dot_prepare(st, p->tiled_dot, x, dy, ws.filters, ws.table_bare, p->drop_col,
                               p->drop_row, ws.tiled_dot);
             ProfScope prof(p, 2, st);
             tiled_dot_run(st, p->tiled_dot, ws.r4, ws.tiled_dot);
@@ -346,7 +346,7 @@ int dau_conv_backward(const dau_conv_plan* p, void* stream, const float* x, cons
         launch_prepare_units(st, w, mu1, mu2, s, 0, flags, p->bucket, true, ws.table_t,
                              (need_mask & param_mask) ? nullptr : ws.status);
         if (p->algo_fwd == DAU_ALGO_TILED) {
-            tiled_gather_prepare(st, p->tiled_dx, dy, ws.filters + 5 * kFilterPlane, ws.table_t, ws.tiled_dx);
+            tiled_gather_prepare(st, p->tiled_dx, dy, ws.filters, true, ws.table_t, ws.tiled_dx);
             ProfScope prof(p, 1, st);
             tiled_gather_run(st, p->tiled_dx, dx, ws.tiled_dx);
         } else {
@@ -381,7 +381,7 @@ int dau_conv_filters(const dau_conv_plan* p, void* stream, const float* sigma, f
     hipStream_t st = static_cast<hipStream_t>(stream);
     // synthesise into a scratch with the fixed plane pitch, then compact to k*k planes
     float* tmp = nullptr;
-    DAU_HIP(hipMalloc(&tmp, sizeof(float) * 6 * kFilterPlane));
+    DAU_HIP(hipMalloc(&tmp, sizeof(float) * kFilterFloats));
     launch_synth_filters(st, sigma, p->blur_k, p->d.flags, tmp);
     const size_t plane = sizeof(float) * p->blur_k * p->blur_k;
     hipError_t e = hipMemcpy2DAsync(filters_out, plane, tmp, sizeof(float) * kFilterPlane, plane, 6, hipMemcpyDeviceToDevice, st);

@@ -21,10 +21,10 @@ struct TiledConfig {
 
 bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, TiledConfig* cfg);
 size_t tiled_gather_workspace_bytes(const TiledConfig& cfg);
-// prepare: blur `in` ([N,Cin,H,W]) with `filter` (k*k taps at kFilterPlane pitch) into the staged
-// pair-interleaved planes and pack the unit table (`table` is indexed [Cin][G][Cout]).
-// run: the gather itself, writing `out` ([N,Cout,H,W]).
-void tiled_gather_prepare(hipStream_t st, const TiledConfig& cfg, const float* in, const float* filter,
+// prepare: blur `in` ([N,Cin,H,W]) with the Gaussian (`filters` = output of launch_synth_filters; `mirrored`
+// selects the flipped kernel of the input-gradient pass) into the staged pair-interleaved planes and pack the
+// unit table (`table` is indexed [Cin][G][Cout]).  run: the gather itself, writing `out` ([N,Cout,H,W]).
+void tiled_gather_prepare(hipStream_t st, const TiledConfig& cfg, const float* in, const float* filters, bool mirrored,
                           const UnitRef* table, void* workspace);
 void tiled_gather_run(hipStream_t st, const TiledConfig& cfg, float* out, void* workspace);
 
@@ -37,9 +37,9 @@ struct TiledDotConfig {
 
 bool tiled_dot_configure(const Shape& sh, int R, int blur_k, TiledDotConfig* cfg);
 size_t tiled_dot_workspace_bytes(const TiledDotConfig& cfg);
-// r4[k][s][g][f] = sum_{n,p} dy'[n,f,p] * bilinear(x * D_k, p + o);  filters4 = Dw,Dmu1,Dmu2,Dsigma planes.
+// r4[k][s][g][f] = sum_{n,p} dy'[n,f,p] * bilinear(x * D_k, p + o);  `filters` = output of launch_synth_filters.
 void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& cfg, const float* x, const float* dy,
-                       const float* filters4, const UnitRef* table_bare, int drop_col, int drop_row, void* workspace);
+                       const float* filters, const UnitRef* table_bare, int drop_col, int drop_row, void* workspace);
 void tiled_dot_run(hipStream_t st, const TiledDotConfig& cfg, float* r4, void* workspace);
 
 }  // namespace dau

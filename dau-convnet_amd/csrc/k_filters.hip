@@ -41,6 +41,33 @@ __global__ void synth_filters_kernel(const float* __restrict__ sigma_dev, int k,
         out[4 * kFilterPlane + t] = (float)((u * u + v * v) * inv_s3 * g / Z - gn * s3);  // Dsigma
         out[5 * kFilterPlane + (k - 1 - j) * k + (k - 1 - i)] = (float)gn;            // Gerr = flip(Gn)
     }
+    // 1-D factors (exact: the masks of single_dim_kernel / forbid_positive_dim1 are separable too)
+    if (lane < k) {
+        const double t = lane - c;
+        double gxs = 0, gys = 0, sx1 = 0, sy1 = 0, sx2 = 0, sy2 = 0;
+        for (int q = 0; q < k; ++q) {
+            const double d = q - c;
+            const double e = exp(-d * d * 0.5 * inv_s2);
+            const double ex = (forbid_pos && d > 0) ? 0.0 : e;
+            const double ey = (single_dim && d != 0) ? 0.0 : e;
+            gxs += ex; gys += ey;
+            sx1 += d * inv_s2 * ex; sy1 += d * inv_s2 * ey;
+            sx2 += d * d * inv_s3 * ex; sy2 += d * d * inv_s3 * ey;
+        }
+        const double e = exp(-t * t * 0.5 * inv_s2);
+        const double gx = ((forbid_pos && t > 0) ? 0.0 : e) / gxs;
+        const double gy = ((single_dim && t != 0) ? 0.0 : e) / gys;
+        const double m1 = sx1 / gxs, m2 = sy1 / gys, m3 = sx2 / gxs + sy2 / gys;   // = s1, s2, s3 of the 2-D form
+        float* taps = out + kTaps1dOffset;
+        taps[kTapGX * kTapPitch + lane] = (float)gx;
+        taps[kTapGY * kTapPitch + lane] = (float)gy;
+        taps[kTapAX * kTapPitch + lane] = (float)((t * inv_s2 - m1) * gx);
+        taps[kTapAY * kTapPitch + lane] = (float)((t * inv_s2 - m2) * gy);
+        taps[kTapCX * kTapPitch + lane] = (float)((t * t * inv_s3 - m3) * gx);
+        taps[kTapBY * kTapPitch + lane] = (float)(t * t * inv_s3 * gy);
+        taps[kTapGXR * kTapPitch + (k - 1 - lane)] = (float)gx;
+        taps[kTapGYR * kTapPitch + (k - 1 - lane)] = (float)gy;
+    }
 }
 
 void launch_synth_filters(hipStream_t st, const float* sigma_dev, int k, int flags, float* filters6) {

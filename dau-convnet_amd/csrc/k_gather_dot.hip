@@ -90,69 +90,104 @@ DotGeometry make_dot_geometry(const Shape& sh, int R) {
 // ------------------------------------------------------------------------------------------------
 // dy[N,F,H,W] -> EP[NP][nfb][EY][EX][32][2]; padded coordinate Y = y + R + 1, zero elsewhere; the
 // unit_testing edge rule (last column / row of the error dropped) is applied here.
-__global__ void pack_error_kernel(const float* __restrict__ dy, int N, int F, int H, int W, int R, int EX, int EY,
-                                  int nfb, int drop_col, int drop_row, float* __restrict__ ep) {
-    const long total = (long)((N + 1) / 2) * nfb * EY * EX * kDF;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int fl = (int)(idx % kDF);
-        long t = idx / kDF;
-        const int X = (int)(t % EX); t /= EX;
-        const int Y = (int)(t % EY); t /= EY;
-        const int fb = (int)(t % nfb);
-        const int np = (int)(t / nfb);
-        const int y = Y - (R + 1), x = X - (R + 1), f = fb * kDF + fl;
-        float a = 0.0f, b = 0.0f;
-        if (y >= 0 && y < H && x >= 0 && x < W && f < F && !(drop_col && x == W - 1) && !(drop_row && y == H - 1)) {
-            const int n0 = 2 * np, n1 = 2 * np + 1;
-            a = dy[(((long)n0 * F + f) * H + y) * W + x];
-            if (n1 < N) b = dy[(((long)n1 * F + f) * H + y) * W + x];
+// One workgroup per (pair, channel block, padded row): 64 coalesced row reads -> LDS -> one contiguous
+// EX*256 B write (a transpose from channel-major to position-major).  HBM bound.
+__global__ void __launch_bounds__(256) pack_error_kernel(const float* __restrict__ dy, int N, int F, int H, int W, int R,
+                                                         int EX, int EY, int nfb, int drop_col, int drop_row,
+                                                         float* __restrict__ ep) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [64 = 32 f x 2 images][W | 1]
+    const int Y = blockIdx.x % EY;
+    const int fb = (blockIdx.x / EY) % nfb;
+    const int np = blockIdx.x / (EY * nfb);
+    const int y = Y - (R + 1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int wp = W | 1;                                   // odd pitch: conflict-free transposed reads
+    const bool rowin = y >= 0 && y < H && !(drop_row && y == H - 1);
+    if (rowin) {
+        for (int r = wave; r < 64; r += nw) {               // r = fl*2 + image
+            const int f = fb * kDF + (r >> 1), n = 2 * np + (r & 1);
+            const bool ok = f < F && n < N;
+            const float* src = dy + (((long)(ok ? n : 0) * F + (ok ? f : 0)) * H + y) * W;
+            for (int x = lane; x < W; x += 64) lds[r * wp + x] = ok ? src[x] : 0.0f;
         }
-        reinterpret_cast<f2*>(ep)[idx] = f2{a, b};
+    }
+    __syncthreads();
+    float* out = ep + ((((size_t)np * nfb + fb) * EY + Y) * EX) * (kDF * 2);
+    const int wlim = drop_col ? W - 1 : W;
+    for (int t = threadIdx.x; t < EX * 64; t += blockDim.x) {
+        const int X = t >> 6, r = t & 63, x = X - (R + 1);
+        out[t] = (rowin && x >= 0 && x < wlim) ? lds[r * wp + x] : 0.0f;
     }
 }
 
-// x[N,S,H,W] -> XK[NP][S][Hp][Wp][4][2], the four derivative-filtered copies, zero padded to whole regions.
-__global__ void __launch_bounds__(256) blur4_pack_kernel(const float* __restrict__ in, const float* __restrict__ filt4,
-                                                         int N, int C, int cstride, int H, int W, int k, int Hp,
-                                                         int Wp, float* __restrict__ xk) {
+// x[N,S,H,W] -> XK[NP][S][Hp][Wp][4][2]: the four derivative-filtered copies (separable form, see dau_common.hpp),
+// zero padded to whole regions.  One workgroup per (pair, channel); raw planes in LDS, then bands of rows:
+// three horizontal passes (gx, ax, cx) -> LDS, five vertical 1-D passes -> 32 B per position.  HBM bound.
+__global__ void __launch_bounds__(512) blur4_pack_kernel(const float* __restrict__ in, const float* __restrict__ taps,
+                                                         int N, int C, int cstride, int H, int W, int k, int Hp, int Wp,
+                                                         int band, float* __restrict__ xk) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int np = blockIdx.x / C, c = blockIdx.x % C;
     const int kr = (k - 1) / 2;
     const int lw = W + 2 * kr, lh = H + 2 * kr;
-    for (int t = threadIdx.x; t < lh * lw; t += blockDim.x) {
-        const int yy = t / lw - kr, xx = t % lw - kr;
-        float a = 0.0f, b = 0.0f;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            const int n0 = 2 * np, n1 = 2 * np + 1;
-            a = in[(((long)n0 * C + c) * H + yy) * W + xx];
-            if (n1 < N) b = in[(((long)n1 * C + c) * H + yy) * W + xx];
+    const int bh = band + 2 * kr;                            // rows of horizontally filtered data per band
+    f2* A = reinterpret_cast<f2*>(lds);                      // raw [lh][lw]
+    f2* B = A + (size_t)lh * lw;                             // [3][bh][W]
+    const float* gx = taps + kTapGX * kTapPitch; const float* gy = taps + kTapGY * kTapPitch;
+    const float* ax = taps + kTapAX * kTapPitch; const float* ay = taps + kTapAY * kTapPitch;
+    const float* cx = taps + kTapCX * kTapPitch; const float* by = taps + kTapBY * kTapPitch;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int n0 = 2 * np, n1 = 2 * np + 1;
+    const float* p0 = in + ((long)n0 * C + c) * H * W;
+    const float* p1 = in + ((long)(n1 < N ? n1 : n0) * C + c) * H * W;
+    const float m1 = n1 < N ? 1.0f : 0.0f;
+    for (int r = wave; r < lh; r += nw) {
+        const int yy = r - kr;
+        const bool rowin = yy >= 0 && yy < H;
+        for (int xl = lane; xl < lw; xl += 64) {
+            const int xx = xl - kr;
+            f2 v = {0.0f, 0.0f};
+            if (rowin && xx >= 0 && xx < W) { v.x = p0[yy * W + xx]; v.y = m1 * p1[yy * W + xx]; }
+            A[r * lw + xl] = v;
         }
-        lds[2 * t] = a; lds[2 * t + 1] = b;
     }
-    __syncthreads();
     f8* out = reinterpret_cast<f8*>(xk) + ((size_t)np * cstride + c) * Hp * Wp;
-    const f2* l2 = reinterpret_cast<const f2*>(lds);
-    for (int t = threadIdx.x; t < Hp * Wp; t += blockDim.x) {
-        const int yy = t / Wp, xx = t % Wp;
-        f2 acc[kNumK];
-#pragma unroll
-        for (int kk = 0; kk < kNumK; ++kk) acc[kk] = f2{0.0f, 0.0f};
-        if (yy < H && xx < W) {
-            for (int j = 0; j < k; ++j)
-                for (int i = 0; i < k; ++i) {
-                    const f2 v = l2[(yy + j) * lw + xx + i];
-#pragma unroll
-                    for (int kk = 0; kk < kNumK; ++kk) {
-                        const float fv = filt4[kk * kFilterPlane + j * k + i];   // wave-uniform -> scalar load
-                        acc[kk].x = fmaf(fv, v.x, acc[kk].x);
-                        acc[kk].y = fmaf(fv, v.y, acc[kk].y);
+    for (int y0 = 0; y0 < Hp; y0 += band) {
+        __syncthreads();
+        // horizontal passes for LDS rows y0 .. y0+bh-1 (image rows y0-kr ..)
+        for (int rr = wave; rr < bh; rr += nw) {
+            const int r = y0 + rr;                          // row of A
+            const bool rowin = r >= kr && r < kr + H;
+            for (int x = lane; x < W; x += 64) {
+                f2 h1 = {0.0f, 0.0f}, h2 = {0.0f, 0.0f}, h3 = {0.0f, 0.0f};
+                if (rowin)
+                    for (int i = 0; i < k; ++i) {
+                        const f2 v = A[r * lw + x + i];
+                        h1 = __builtin_elementwise_fma(v, f2{gx[i], gx[i]}, h1);
+                        h2 = __builtin_elementwise_fma(v, f2{ax[i], ax[i]}, h2);
+                        h3 = __builtin_elementwise_fma(v, f2{cx[i], cx[i]}, h3);
                     }
-                }
+                B[(0 * bh + rr) * W + x] = h1; B[(1 * bh + rr) * W + x] = h2; B[(2 * bh + rr) * W + x] = h3;
+            }
         }
-        f8 o;
-#pragma unroll
-        for (int kk = 0; kk < kNumK; ++kk) { o[2 * kk] = acc[kk].x; o[2 * kk + 1] = acc[kk].y; }
-        out[t] = o;
+        __syncthreads();
+        for (int yr = wave; yr < band; yr += nw) {
+            const int yy = y0 + yr;
+            if (yy >= Hp) break;
+            for (int xx = lane; xx < Wp; xx += 64) {
+                f2 dw = {0.0f, 0.0f}, d1 = {0.0f, 0.0f}, d2 = {0.0f, 0.0f}, ds = {0.0f, 0.0f};
+                if (yy < H && xx < W)
+                    for (int j = 0; j < k; ++j) {
+                        const f2 b1 = B[(0 * bh + yr + j) * W + xx], b2 = B[(1 * bh + yr + j) * W + xx], b3 = B[(2 * bh + yr + j) * W + xx];
+                        dw = __builtin_elementwise_fma(b1, f2{gy[j], gy[j]}, dw);
+                        d1 = __builtin_elementwise_fma(b2, f2{gy[j], gy[j]}, d1);
+                        d2 = __builtin_elementwise_fma(b1, f2{ay[j], ay[j]}, d2);
+                        ds = __builtin_elementwise_fma(b3, f2{gy[j], gy[j]}, ds);
+                        ds = __builtin_elementwise_fma(b1, f2{by[j], by[j]}, ds);
+                    }
+                out[(size_t)yy * Wp + xx] = f8{dw.x, dw.y, d1.x, d1.y, d2.x, d2.y, ds.x, ds.y};
+            }
+        }
     }
 }
 
@@ -468,6 +503,15 @@ DotLayout dot_layout(const TiledDotConfig& c, const DotGeometry& g) {
     return l;
 }
 
+// rows per band of blur4_pack_kernel so that raw planes + three filtered bands stay below ~72 KiB (two workgroups per CU)
+void blur4_plan(int H, int W, int k, int Hp, int* band, size_t* lds) {
+    const size_t raw = (size_t)(H + k - 1) * (W + k - 1) * 8;
+    int b = Hp;
+    while (b > 8 && raw + (size_t)3 * (b + k - 1) * W * 8 > 72 * 1024) b = (b + 1) / 2;
+    *band = b;
+    *lds = raw + (size_t)3 * (b + k - 1) * W * 8;
+}
+
 template <int GP, int AS>
 void launch_dot(hipStream_t st, const DotArgs& a, int grid, size_t lds) {
     auto kern = gather_dot_kernel<GP, AS>;
@@ -487,8 +531,11 @@ bool tiled_dot_configure(const Shape& sh, int R, int blur_k, TiledDotConfig* cfg
     if (2 * g.tile_bytes > 160 * 1024) return false;             // R = 4 only for now (8x8 regions)
     // immediates of the unrolled column walk must fit 16 bits
     if ((size_t)g.epitch * kDF * 8 + (kRW + 1) * kDF * 8 > 65535) return false;
-    const size_t blur_lds = (size_t)(sh.H + blur_k - 1) * (sh.W + blur_k - 1) * 8;
-    if (blur_lds > 64 * 1024) return false;
+    {
+        int band; size_t blur_lds;
+        blur4_plan(sh.H, sh.W, blur_k, g.Hp, &band, &blur_lds);
+        if (blur_lds > 150 * 1024) return false;
+    }
     TiledDotConfig c{};
     c.sh = sh; c.R = R; c.blur_k = blur_k; c.NP = (sh.N + 1) / 2; c.variant = g.GP;
     *cfg = c;
@@ -499,7 +546,7 @@ size_t tiled_dot_workspace_bytes(const TiledDotConfig& c) {
     return dot_layout(c, make_dot_geometry(c.sh, c.R)).total;
 }
 
-void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, const float* dy, const float* filters4,
+void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, const float* dy, const float* filters,
                        const UnitRef* table_bare, int drop_col, int drop_row, void* workspace) {
     const DotGeometry g = make_dot_geometry(c.sh, c.R);
     const DotLayout l = dot_layout(c, g);
@@ -507,18 +554,22 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
     const Shape& s = c.sh;
     const int s_pad = g.nsb * g.sblock;
     {
-        const long total = (long)c.NP * g.nfb * g.EY * g.EX * kDF;
-        const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-        hipLaunchKernelGGL(pack_error_kernel, dim3(grid), dim3(256), 0, st, dy, s.N, s.F, s.H, s.W, c.R, g.EX, g.EY, g.nfb,
-                           drop_col, drop_row, reinterpret_cast<float*>(ws + l.ep_off));
+        const size_t lds = (size_t)64 * (s.W | 1) * 4;
+        hipLaunchKernelGGL(pack_error_kernel, dim3(c.NP * g.nfb * g.EY), dim3(256), lds, st, dy, s.N, s.F, s.H, s.W, c.R, g.EX,
+                           g.EY, g.nfb, drop_col, drop_row, reinterpret_cast<float*>(ws + l.ep_off));
     }
     {
         // channels beyond S (padding of the last input-channel block) must read as zero
         if (s_pad != s.S) (void)hipMemsetAsync(ws + l.xk_off, 0, (size_t)c.NP * s_pad * g.Hp * g.Wp * 32, st);
-        const size_t blur_lds = (size_t)(s.H + c.blur_k - 1) * (s.W + c.blur_k - 1) * 8;
-        // XK is indexed [np][s_pad][Hp][Wp]: launch one block per (np, s) and let the kernel use the padded stride
-        hipLaunchKernelGGL(blur4_pack_kernel, dim3(c.NP * s.S), dim3(256), blur_lds, st, x, filters4, s.N, s.S, s_pad, s.H, s.W,
-                           c.blur_k, g.Hp, g.Wp, reinterpret_cast<float*>(ws + l.xk_off));
+        int band; size_t blur_lds;
+        blur4_plan(s.H, s.W, c.blur_k, g.Hp, &band, &blur_lds);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blur4_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(blur4_pack_kernel, dim3(c.NP * s.S), dim3(512), blur_lds, st, x, filters + kTaps1dOffset, s.N, s.S, s_pad,
+                           s.H, s.W, c.blur_k, g.Hp, g.Wp, band, reinterpret_cast<float*>(ws + l.xk_off));
     }
     {
         const long total = (long)s_pad * g.GP * g.nfb * 64;

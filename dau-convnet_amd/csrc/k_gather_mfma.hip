@@ -70,44 +70,58 @@ Geometry make_geometry(int H, int W, int R) {
 
 // ------------------------------------------------------------------------------------------------
 // blur + pack: in[N,C,H,W] -> staged[NP][C][rows][pitch][2] (zero border of R on the left/top,
-// >= R+1 on the right/bottom), blurred with the k x k filter.  One workgroup per (pair, channel).
+// >= R+1 on the right/bottom), blurred with the separable Gaussian gx (x) gy.  One workgroup per
+// (image pair, channel): raw planes -> LDS, horizontal pass -> LDS, vertical pass -> coalesced rows.
+// HBM bound: reads the NCHW input once, writes the staged copy once.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) blur_pack_kernel(const float* __restrict__ in, const float* __restrict__ filt,
-                                                        int N, int C, int H, int W, int R, int k, int rows,
+__global__ void __launch_bounds__(512) blur_pack_kernel(const float* __restrict__ in, const float* __restrict__ taps,
+                                                        int mirrored, int N, int C, int H, int W, int R, int k, int rows,
                                                         int pitch, size_t plane_floats, float* __restrict__ staged) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int np = blockIdx.x / C, c = blockIdx.x % C;
     const int kr = (k - 1) / 2;
-    const int lw = W + 2 * kr;                 // LDS row width (positions), both images interleaved
-    const int lh = H + 2 * kr;
-    // raw planes with a zero halo of the blur radius, interleaved [y][x][2]
-    for (int t = threadIdx.x; t < lh * lw; t += blockDim.x) {
-        const int yy = t / lw - kr, xx = t % lw - kr;
-        float a = 0.0f, b = 0.0f;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            const int n0 = 2 * np, n1 = 2 * np + 1;
-            a = in[(((long)n0 * C + c) * H + yy) * W + xx];
-            if (n1 < N) b = in[(((long)n1 * C + c) * H + yy) * W + xx];
+    const int lw = W + 2 * kr, lh = H + 2 * kr;
+    f2* A = reinterpret_cast<f2*>(lds);          // raw, zero halo of the blur radius   [lh][lw]
+    f2* B = A + (size_t)lh * lw;                  // after the horizontal pass           [lh][W]
+    const float* gx = taps + (mirrored ? kTapGXR : kTapGX) * kTapPitch;
+    const float* gy = taps + (mirrored ? kTapGYR : kTapGY) * kTapPitch;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int n0 = 2 * np, n1 = 2 * np + 1;
+    const float* p0 = in + ((long)n0 * C + c) * H * W;
+    const float* p1 = in + ((long)(n1 < N ? n1 : n0) * C + c) * H * W;
+    const float m1 = n1 < N ? 1.0f : 0.0f;        // odd batch: the second image of the last pair is zero
+    for (int r = wave; r < lh; r += nw) {
+        const int yy = r - kr;
+        const bool rowin = yy >= 0 && yy < H;
+        for (int xl = lane; xl < lw; xl += 64) {
+            const int xx = xl - kr;
+            f2 v = {0.0f, 0.0f};
+            if (rowin && xx >= 0 && xx < W) { v.x = p0[yy * W + xx]; v.y = m1 * p1[yy * W + xx]; }
+            A[r * lw + xl] = v;
         }
-        lds[2 * t] = a; lds[2 * t + 1] = b;
     }
     __syncthreads();
-    float* out = staged + ((size_t)np * C + c) * plane_floats;
-    const f2* l2 = reinterpret_cast<const f2*>(lds);
-    for (int t = threadIdx.x; t < rows * pitch; t += blockDim.x) {
-        const int row = t / pitch, col = t % pitch;
-        const int yy = row - R, xx = col - R;
-        f2 acc = {0.0f, 0.0f};
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            for (int j = 0; j < k; ++j)
-                for (int i = 0; i < k; ++i) {
-                    const float fv = filt[j * k + i];          // wave-uniform -> scalar load
-                    const f2 v = l2[(yy + j) * lw + xx + i];
-                    acc.x = fmaf(fv, v.x, acc.x);
-                    acc.y = fmaf(fv, v.y, acc.y);
-                }
+    for (int r = wave; r < lh; r += nw) {
+        const bool rowin = r >= kr && r < kr + H;
+        for (int x = lane; x < W; x += 64) {
+            f2 acc = {0.0f, 0.0f};
+            if (rowin)
+                for (int i = 0; i < k; ++i) acc = __builtin_elementwise_fma(A[r * lw + x + i], f2{gx[i], gx[i]}, acc);
+            B[r * W + x] = acc;
         }
-        reinterpret_cast<f2*>(out)[t] = acc;
+    }
+    __syncthreads();
+    f2* out = reinterpret_cast<f2*>(staged + ((size_t)np * C + c) * plane_floats);
+    for (int row = wave; row < rows; row += nw) {
+        const int yy = row - R;
+        const bool rowin = yy >= 0 && yy < H;
+        for (int col = lane; col < pitch; col += 64) {
+            const int xx = col - R;
+            f2 acc = {0.0f, 0.0f};
+            if (rowin && xx >= 0 && xx < W)
+                for (int j = 0; j < k; ++j) acc = __builtin_elementwise_fma(B[(yy + j) * W + xx], f2{gy[j], gy[j]}, acc);
+            out[row * pitch + col] = acc;
+        }
     }
 }
 
@@ -398,6 +412,10 @@ void launch_variant(hipStream_t st, const GatherArgs& a, int grid, size_t lds) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T::kThreads), lds, st, a);
 }
 
+size_t blur_pack_lds_bytes(int H, int W, int k) {
+    return ((size_t)(H + k - 1) * (W + k - 1) + (size_t)(H + k - 1) * W) * 8;
+}
+
 size_t ut_stride_bytes(int G) { return round_up((size_t)G * kFB * kUnitDwords * 4, 1024); }
 
 size_t lds_bytes(const TiledConfig& c, const Geometry& g) {
@@ -426,9 +444,8 @@ bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R
     c.NP = (N + 1) / 2;
     c.rows = g.rows; c.pitch = g.pitch; c.tiles_x = g.tx; c.tiles_y = g.ty; c.fblock = kFB; c.variant = variant;
     if (lds_bytes(c, g) > 160 * 1024) return false;
-    // blur_pack stages both raw planes (+ blur halo) in LDS
-    const size_t blur_lds = (size_t)(H + blur_k - 1) * (W + blur_k - 1) * 8;
-    if (blur_lds > 64 * 1024) return false;
+    // blur_pack keeps both raw planes (+ blur halo) and the horizontally filtered rows in LDS
+    if (blur_pack_lds_bytes(H, W, blur_k) > 150 * 1024) return false;
     *cfg = c;
     return true;
 }
@@ -439,14 +456,19 @@ size_t tiled_gather_workspace_bytes(const TiledConfig& c) {
     return round_up((size_t)c.NP * c.Cin * g.plane_bytes, 256) + round_up(nfb * c.Cin * ut_stride_bytes(c.G), 256);
 }
 
-void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in, const float* filter,
+void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in, const float* filters, bool mirrored,
                           const UnitRef* table, void* workspace) {
     const Geometry g = make_geometry(c.H, c.W, c.R);
     char* staged = static_cast<char*>(workspace);
     char* packed = staged + round_up((size_t)c.NP * c.Cin * g.plane_bytes, 256);
-    const size_t blur_lds = (size_t)(c.H + c.blur_k - 1) * (c.W + c.blur_k - 1) * 8;
-    hipLaunchKernelGGL(blur_pack_kernel, dim3(c.NP * c.Cin), dim3(256), blur_lds, st, in, filter, c.N, c.Cin, c.H, c.W,
-                       c.R, c.blur_k, g.rows, g.pitch, g.plane_bytes / 4, reinterpret_cast<float*>(staged));
+    const size_t blur_lds = blur_pack_lds_bytes(c.H, c.W, c.blur_k);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blur_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(blur_pack_kernel, dim3(c.NP * c.Cin), dim3(512), blur_lds, st, in, filters + kTaps1dOffset, mirrored ? 1 : 0,
+                       c.N, c.Cin, c.H, c.W, c.R, c.blur_k, g.rows, g.pitch, g.plane_bytes / 4, reinterpret_cast<float*>(staged));
     const int nfb = (c.Cout + kFB - 1) / kFB;
     const size_t uts = ut_stride_bytes(c.G);
     // packed slices are padded to whole KiB; zero the padding once per call together with the payload
