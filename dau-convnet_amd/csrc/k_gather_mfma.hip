@@ -38,7 +38,7 @@ typedef __attribute__((address_space(1))) const void* glb_ptr_t;
 namespace {
 
 constexpr int kFB = 4;            // output channels per workgroup
-constexpr int kUnitDwords = 8;    // packed unit: {w00,off,w01,off,w10,off,w11,off}
+constexpr int kUnitDwords = 8;    // packed unit: {w00,off,w01,off,w10,offT,w11,offT} (offT: displacement in the transposed strip)
 
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -47,6 +47,8 @@ struct Geometry {
     int rows, pitch;          // staged plane
     int tx, ty;               // regular 8x8 tiles
     int edge;                 // 1: W%8==0 && H%8==0 -> separate edge tiles; 0: regular tiles cover (H+1)x(W+1)
+    int strip_pitch;          // EDGE: rows of the transposed strip (columns W .. W+2R of the plane, column-major)
+    size_t strip_off;         // byte offset of the strip inside a staged plane
     size_t plane_bytes;       // padded to 1 KiB (one global_load_lds wave instruction)
 };
 
@@ -62,7 +64,9 @@ Geometry make_geometry(int H, int W, int R) {
     while (pitch % 32 != 8) ++pitch;
     g.pitch = pitch;
     g.rows = need_rows;
-    g.plane_bytes = round_up((size_t)g.rows * g.pitch * 8, 1024);
+    g.strip_pitch = g.rows;
+    g.strip_off = (size_t)g.rows * g.pitch * 8;
+    g.plane_bytes = round_up(g.strip_off + (g.edge ? (size_t)(2 * R + 1) * g.strip_pitch * 8 : 0), 1024);
     return g;
 }
 
@@ -76,7 +80,8 @@ Geometry make_geometry(int H, int W, int R) {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(512) blur_pack_kernel(const float* __restrict__ in, const float* __restrict__ taps,
                                                         int mirrored, int N, int C, int H, int W, int R, int k, int rows,
-                                                        int pitch, size_t plane_floats, float* __restrict__ staged) {
+                                                        int pitch, int strip_cols, size_t plane_floats,
+                                                        float* __restrict__ staged) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int np = blockIdx.x / C, c = blockIdx.x % C;
     const int kr = (k - 1) / 2;
@@ -112,6 +117,7 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const float* __restrict_
     }
     __syncthreads();
     f2* out = reinterpret_cast<f2*>(staged + ((size_t)np * C + c) * plane_floats);
+    f2* strip = out + (size_t)rows * pitch;
     for (int row = wave; row < rows; row += nw) {
         const int yy = row - R;
         const bool rowin = yy >= 0 && yy < H;
@@ -121,6 +127,9 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const float* __restrict_
             if (rowin && xx >= 0 && xx < W)
                 for (int j = 0; j < k; ++j) acc = __builtin_elementwise_fma(B[(yy + j) * W + xx], f2{gy[j], gy[j]}, acc);
             out[row * pitch + col] = acc;
+            // columns W .. W+2R are stored a second time column-major: the edge-column tile of the gather reads a
+            // vertical run of positions, which is bank-conflict free only in this orientation
+            if (strip_cols > 0 && col >= W && col < W + strip_cols) strip[(col - W) * rows + row] = acc;
         }
     }
 }
@@ -128,8 +137,8 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // unit packing: UnitRef[Cin][G][Cout] -> packed[FBn][Cin] slices of [G][kFB][8 dwords], each slice padded to 1 KiB
 // ------------------------------------------------------------------------------------------------
-__global__ void pack_units_kernel(const UnitRef* __restrict__ table, int Cin, int G, int Cout, int pitch,
-                                  int ut_stride_dwords, unsigned int* __restrict__ packed) {
+__global__ void pack_units_kernel(const UnitRef* __restrict__ table, int Cin, int G, int Cout, int pitch, int R,
+                                  int strip_pitch, int ut_stride_dwords, unsigned int* __restrict__ packed) {
     const int nfb = (Cout + kFB - 1) / kFB;
     const long total = (long)nfb * Cin * G * kFB;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -141,11 +150,12 @@ __global__ void pack_units_kernel(const UnitRef* __restrict__ table, int Cin, in
         UnitRef u{0, 0, 0.0f, 0.0f, 0.0f, 0.0f};
         if (f < Cout) u = table[((long)c * G + g) * Cout + f];
         const int off = (u.oy * pitch + u.ox) * 8;   // byte displacement inside a staged plane
+        const int offt = ((u.ox + R) * strip_pitch + u.oy) * 8;   // ... and inside its transposed strip
         unsigned int* dst = packed + ((long)fb * Cin + c) * ut_stride_dwords + (g * kFB + fi) * kUnitDwords;
         dst[0] = __float_as_uint(u.w00); dst[1] = (unsigned)off;
         dst[2] = __float_as_uint(u.w01); dst[3] = (unsigned)off;
-        dst[4] = __float_as_uint(u.w10); dst[5] = (unsigned)off;
-        dst[6] = __float_as_uint(u.w11); dst[7] = (unsigned)off;
+        dst[4] = __float_as_uint(u.w10); dst[5] = (unsigned)offt;
+        dst[6] = __float_as_uint(u.w11); dst[7] = (unsigned)offt;
     }
 }
 
@@ -159,6 +169,7 @@ struct GatherArgs {
     int N, Cin, Cout, G, H, W, R;
     int nfb;                   // ceil(Cout / kFB)
     unsigned plane_bytes, ut_stride;
+    unsigned strip_off;        // byte offset of the transposed strip inside a plane
     unsigned zpitch;           // epilogue Z-plane pitch (floats)
     int debug;                 // timing experiments only (DAU_GATHER_DEBUG): 1 = no plane refills after the first two
 };
@@ -196,6 +207,10 @@ constexpr int kBatch = 4;   // tiles per batch
 
 template <class T, int TX, int PITCH, int TILE>
 __device__ __forceinline__ void load_tile(f2& dst, unsigned addr, unsigned addr_e0, unsigned addr_e1) {
+#ifdef DAU_DIAG_NOLDS   // timing diagnosis only: no LDS tile reads (results are garbage)
+    asm volatile("" : "=v"(dst) : "v"(addr), "v"(addr_e0), "v"(addr_e1));
+    return;
+#endif
     if constexpr (TILE < T::kRegular)
         asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(tile_imm<TX, PITCH>(TILE)) : "memory");
     else if constexpr (TILE == T::kRegular)
@@ -214,38 +229,61 @@ __device__ __forceinline__ void load_batch(f2 (&dst)[kBatch], unsigned addr, uns
      ...);
 }
 
-template <class T, int TX, int PITCH, int FIRST, int COUNT, int KP, int BATCH>
-__device__ __forceinline__ void unit_batches(f4 (&acc)[KP][2], f2 (&xv)[2][kBatch], float wv, unsigned addr,
-                                             unsigned addr_e0, unsigned addr_e1) {
+// A group of U consecutive units (same input channel, unit indices g .. g+U-1) runs as one straight-line block:
+// the batch list of all U units is flattened and the ds_read_b64 of flattened batch n+1 are issued before the MFMAs
+// of batch n (counted lgkmcnt), so the LDS latency is exposed once per group instead of once per unit.
+template <class T, int TX, int PITCH, int FIRST, int COUNT, int KP, int U, int FB>
+__device__ __forceinline__ void group_batches(f4 (&acc)[KP][2], f2 (&xv)[2][kBatch], const float (&wv)[U],
+                                              const unsigned (&addr)[U], const unsigned (&addr_e0)[U],
+                                              const unsigned (&addr_e1)[U]) {
     constexpr int NB = (COUNT + kBatch - 1) / kBatch;
-    constexpr int left = COUNT - (BATCH + 1) * kBatch;
-    constexpr int next = (BATCH + 1 < NB) ? (left < kBatch ? left : kBatch) : 0;
-    if constexpr (BATCH + 1 < NB)
-        load_batch<T, TX, PITCH, FIRST, COUNT, BATCH + 1>(xv[(BATCH + 1) & 1], addr, addr_e0, addr_e1,
-                                                          std::make_integer_sequence<int, kBatch>{});
+    constexpr int u = FB / NB, b = FB % NB;
+    constexpr bool more = FB + 1 < U * NB;
+    constexpr int nu = more ? (FB + 1) / NB : 0, nb = more ? (FB + 1) % NB : 0;
+    constexpr int left = COUNT - nb * kBatch;
+    constexpr int next = more ? (left < kBatch ? left : kBatch) : 0;
+    if constexpr (more)
+        load_batch<T, TX, PITCH, FIRST, COUNT, nb>(xv[(FB + 1) & 1], addr[nu], addr_e0[nu], addr_e1[nu],
+                                                   std::make_integer_sequence<int, kBatch>{});
     lds_wait<next>();
 #pragma unroll
     for (int j = 0; j < kBatch; ++j) {
-        const int i = BATCH * kBatch + j;
+        const int i = b * kBatch + j;
         if (i < COUNT) {
-            acc[i][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv, xv[BATCH & 1][j].x, acc[i][0], 0, 0, 0);
-            acc[i][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv, xv[BATCH & 1][j].y, acc[i][1], 0, 0, 0);
+            acc[i][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[u], xv[FB & 1][j].x, acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv[u], xv[FB & 1][j].y, acc[i][1], 0, 0, 0);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (BATCH + 1 < NB) unit_batches<T, TX, PITCH, FIRST, COUNT, KP, BATCH + 1>(acc, xv, wv, addr, addr_e0, addr_e1);
+    if constexpr (more) group_batches<T, TX, PITCH, FIRST, COUNT, KP, U, FB + 1>(acc, xv, wv, addr, addr_e0, addr_e1);
 }
 
-template <int TX, int TY, int PITCH, bool EDGE, int SPLIT, int PART, int KP>
-__device__ __forceinline__ void unit_step(f4 (&acc)[KP][2], float wv, unsigned addr, unsigned addr_e0,
-                                          unsigned addr_e1) {
+// ut_addr: LDS address of this lane's slot in the first unit's table entry; entries are unit_pitch bytes apart.
+template <int TX, int TY, int PITCH, bool EDGE, int SPLIT, int PART, int KP, int U>
+__device__ __forceinline__ void unit_group(f4 (&acc)[KP][2], unsigned ut_addr, unsigned unit_pitch, unsigned pbase,
+                                           unsigned lane_base, unsigned ebase0, unsigned ebase1) {
     using T = GatherTraits<TX, TY, PITCH, EDGE, SPLIT>;
     constexpr int first = PART * T::kPerPart;
     constexpr int count = (first + KP <= T::kTiles) ? KP : (T::kTiles > first ? T::kTiles - first : 0);
     if constexpr (count > 0) {
+        f2 wo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) asm volatile("ds_read_b64 %0, %1" : "=v"(wo[u]) : "v"(ut_addr + u * unit_pitch) : "memory");
+        lds_wait<0>();
+        float wv[U];
+        unsigned addr[U], addr_e0[U], addr_e1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            wv[u] = wo[u].x;
+            // lanes 0,1 of every quad hold the plane displacement, lanes 2,3 the strip displacement: broadcast both
+            const unsigned oraw = __float_as_uint(wo[u].y);
+            const unsigned off = (unsigned)__builtin_amdgcn_mov_dpp((int)oraw, 0x00, 0xf, 0xf, true) + pbase;
+            const unsigned offt = (unsigned)__builtin_amdgcn_mov_dpp((int)oraw, 0xAA, 0xf, 0xf, true) + pbase;
+            addr[u] = lane_base + off; addr_e0[u] = ebase0 + off; addr_e1[u] = ebase1 + offt;
+        }
         f2 xv[2][kBatch];
-        load_batch<T, TX, PITCH, first, count, 0>(xv[0], addr, addr_e0, addr_e1, std::make_integer_sequence<int, kBatch>{});
-        unit_batches<T, TX, PITCH, first, count, KP, 0>(acc, xv, wv, addr, addr_e0, addr_e1);
+        load_batch<T, TX, PITCH, first, count, 0>(xv[0], addr[0], addr_e0[0], addr_e1[0], std::make_integer_sequence<int, kBatch>{});
+        group_batches<T, TX, PITCH, first, count, KP, U, 0>(acc, xv, wv, addr, addr_e0, addr_e1);
     }
 }
 
@@ -270,19 +308,18 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
     const int R = a.R, H = a.H, W = a.W;
     const int ly = lane >> 3, lx = lane & 7;
     const unsigned lane_base = (unsigned)(((ly + R) * PITCH + (lx + R)) * 8);
-    // edge tiles: the column x = W (y = 0..H) followed by the row y = H (x = 0..W-1)
+    // Edge tiles (the extra row / column of Z): tile E0 = the row y = H, x = 0..W-1, read from the plane (consecutive
+    // lanes, consecutive addresses); tile E1 = the column x = W, y = 0..H, read from the column-major strip so that its
+    // vertical run of positions is conflict-free as well (from the row-major plane it was an 8-way bank conflict and
+    // made LDS, not the matrix pipe, the busiest resource).
     int ey[2] = {0, 0}, ex[2] = {0, 0};
     bool evalid[2] = {false, false};
     if (EDGE) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int idx = e * 64 + lane;
-            if (idx <= H) { ey[e] = idx; ex[e] = W; evalid[e] = true; }
-            else if (idx < H + 1 + W) { ey[e] = H; ex[e] = idx - (H + 1); evalid[e] = true; }
-        }
+        if (lane < W) { ey[0] = H; ex[0] = lane; evalid[0] = true; }
+        if (lane <= H) { ey[1] = lane; ex[1] = W; evalid[1] = true; }
     }
     const unsigned ebase0 = (unsigned)(((ey[0] + R) * PITCH + ex[0] + R) * 8);
-    const unsigned ebase1 = (unsigned)(((ey[1] + R) * PITCH + ex[1] + R) * 8);
+    const unsigned ebase1 = (unsigned)(a.strip_off + (ey[1] + R) * 8);
 
     const unsigned plane_bytes = a.plane_bytes, ut_stride = a.ut_stride;
     const char* src_planes = a.staged + (size_t)np * a.Cin * plane_bytes;
@@ -309,23 +346,19 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
     issue(0, 0);
     for (int c = 0; c < a.Cin; ++c) {
         const int buf = c & 1;
+#ifndef DAU_DIAG_NOBARRIER
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // plane c is in LDS for everyone; everyone is done reading plane c-1
+#endif
         if (c + 1 < a.Cin && !((a.debug & 1) && c >= 1)) issue(c + 1, buf ^ 1);
         const unsigned pbase = buf * plane_bytes;
-        const char* ut = smem + ut_base + buf * ut_stride + (fi * kUnitDwords + (lane & 3) * 2) * 4;
-        const unsigned ut_addr = (unsigned)(ut - smem);
-        f2 wo;
-        asm volatile("ds_read_b64 %0, %1" : "=v"(wo) : "v"(ut_addr) : "memory");
-        for (int g = 0; g < a.G; ++g) {
-            lds_wait<0>();
-            const float wv = wo.x;
-            const unsigned off = __float_as_uint(wo.y) + pbase;
-            // next unit's {weight, displacement} is fetched under this unit's MFMAs
-            if (g + 1 < a.G)
-                asm volatile("ds_read_b64 %0, %1" : "=v"(wo) : "v"(ut_addr + (g + 1) * (kFB * kUnitDwords * 4)) : "memory");
-            unit_step<TX, TY, PITCH, EDGE, SPLIT, PART, KP>(acc, wv, lane_base + off, ebase0 + off, ebase1 + off);
-        }
+        const unsigned ut_addr = ut_base + buf * ut_stride + (fi * kUnitDwords + (lane & 3) * 2) * 4;
+        constexpr unsigned unit_pitch = kFB * kUnitDwords * 4;
+        int g = 0;
+        for (; g + 4 <= a.G; g += 4)
+            unit_group<TX, TY, PITCH, EDGE, SPLIT, PART, KP, 4>(acc, ut_addr + g * unit_pitch, unit_pitch, pbase, lane_base, ebase0, ebase1);
+        for (; g < a.G; ++g)
+            unit_group<TX, TY, PITCH, EDGE, SPLIT, PART, KP, 1>(acc, ut_addr + g * unit_pitch, unit_pitch, pbase, lane_base, ebase0, ebase1);
     }
 
     // ---- epilogue: out[p] = Z0[p] + Z1[p+(0,1)] + Z2[p+(1,0)] + Z3[p+(1,1)] through LDS ---------------
@@ -468,14 +501,16 @@ void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in,
         attr_set = true;
     }
     hipLaunchKernelGGL(blur_pack_kernel, dim3(c.NP * c.Cin), dim3(512), blur_lds, st, in, filters + kTaps1dOffset, mirrored ? 1 : 0,
-                       c.N, c.Cin, c.H, c.W, c.R, c.blur_k, g.rows, g.pitch, g.plane_bytes / 4, reinterpret_cast<float*>(staged));
+                       c.N, c.Cin, c.H, c.W, c.R, c.blur_k, g.rows, g.pitch, g.edge ? 2 * c.R + 1 : 0, g.plane_bytes / 4,
+                       reinterpret_cast<float*>(staged));
     const int nfb = (c.Cout + kFB - 1) / kFB;
     const size_t uts = ut_stride_bytes(c.G);
     // packed slices are padded to whole KiB; zero the padding once per call together with the payload
     (void)hipMemsetAsync(packed, 0, (size_t)nfb * c.Cin * uts, st);
     const long total = (long)nfb * c.Cin * c.G * kFB;
     const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-    hipLaunchKernelGGL(pack_units_kernel, dim3(grid), dim3(256), 0, st, table, c.Cin, c.G, c.Cout, g.pitch, (int)(uts / 4),
+    hipLaunchKernelGGL(pack_units_kernel, dim3(grid), dim3(256), 0, st, table, c.Cin, c.G, c.Cout, g.pitch, c.R, g.strip_pitch,
+                       (int)(uts / 4),
                        reinterpret_cast<unsigned int*>(packed));
 }
 
@@ -488,6 +523,7 @@ void tiled_gather_run(hipStream_t st, const TiledConfig& c, float* out, void* wo
     a.N = c.N; a.Cin = c.Cin; a.Cout = c.Cout; a.G = c.G; a.H = c.H; a.W = c.W; a.R = c.R;
     a.nfb = (c.Cout + kFB - 1) / kFB;
     a.plane_bytes = (unsigned)g.plane_bytes;
+    a.strip_off = (unsigned)g.strip_off;
     a.ut_stride = (unsigned)ut_stride_bytes(c.G);
     a.zpitch = (unsigned)(c.W + 2);
     a.debug = getenv("DAU_GATHER_DEBUG") ? atoi(getenv("DAU_GATHER_DEBUG")) : 0;
