@@ -58,8 +58,12 @@ def main():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the operator)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the exchange path is used even for one rank, so that a 1-GPU box can
+    # rehearse exactly what N>1 runs: RCCL init, split backward, async all-reduce
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from dau_conv import _capi
@@ -81,20 +85,22 @@ def main():
 
     plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, flags=_capi.FLAG_USE_INTERPOLATION, algo=args.algo,
                       sigma_hint=0.5, mu_learning_rate_factor=1.0)
-    from dau_conv.distributed import GradBucket
-    bucket = GradBucket((1, S, G, F), dev) if world > 1 else None
+    from dau_conv.distributed import OverlappedBackward
+    exchange = OverlappedBackward((1, S, G, F), dev) if use_dist else None
 
     def step():
         y = plan.forward(x, w, mu1, mu2, sigma)
-        dx, dw, dmu1, dmu2, dsigma = plan.backward(x, dy, w, mu1, mu2, sigma)
-        if world > 1:
-            # batch-sharded data parallelism: one all-reduce of [dw, dmu1, dmu2, dsigma] over RCCL/xGMI
-            bucket.pack(dw, dmu1, dmu2, dsigma)
-            bucket.all_reduce()
+        if use_dist:
+            # batch-sharded data parallelism: one all-reduce of [dw|dmu1|dmu2|dsigma] over RCCL/xGMI, issued after the
+            # gather-dot pass and hidden under the dx pass
+            dx = exchange.run(lambda need: plan.backward(x, dy, w, mu1, mu2, sigma, need_mask=need))
+            exchange.wait()
+        else:
+            dx = plan.backward(x, dy, w, mu1, mu2, sigma)[0]
         return y, dx
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -109,7 +115,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     prof = plan.profile_end()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -165,7 +171,7 @@ def main():
                                algo_forward=plan.info["algo_forward"], algo_backward=plan.info["algo_backward"]),
                    roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

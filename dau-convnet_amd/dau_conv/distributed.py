@@ -46,3 +46,36 @@ def all_reduce_param_grads(dw, dmu1, dmu2, dsigma, bucket=None, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         bucket.all_reduce(group=group)
     return bucket.views()
+
+
+class OverlappedBackward(object):
+    """Backward of one batch shard with the gradient exchange hidden under the dx pass.
+
+    dau_conv_backward is called twice through its need mask: first for [dw, dmu1, dmu2, dsigma] (the gather-dot
+    pass), whose flat bucket goes out on the collective's own stream (async all-reduce), then for dx (the gather-sum
+    pass over the mirrored error), which runs while the 4*S*G*F floats travel over xGMI.  `wait()` joins the two.
+
+    `backward_fn(need_mask) -> (dx, dw, dmu1, dmu2, dsigma)` is `Plan.backward` bound to its tensors; the CPU tests
+    drive the same class with the oracle through the same signature.
+    """
+
+    def __init__(self, param_shape, device, group=None):
+        self.bucket = GradBucket(param_shape, device)
+        self.group = group
+        self._work = None
+
+    def run(self, backward_fn, need_dx=True):
+        from ._capi import NEED_DX, NEED_DW, NEED_DMU1, NEED_DMU2, NEED_DSIGMA
+        _, dw, dmu1, dmu2, dsigma = backward_fn(NEED_DW | NEED_DMU1 | NEED_DMU2 | NEED_DSIGMA)
+        self.bucket.pack(dw, dmu1, dmu2, dsigma)
+        if dist.is_available() and dist.is_initialized():
+            self._work = self.bucket.all_reduce(group=self.group, async_op=True)
+        dx = backward_fn(NEED_DX)[0] if need_dx else None
+        return dx
+
+    def wait(self):
+        """Make the current stream wait for the exchange; returns the reduced (dw, dmu1, dmu2, dsigma) views."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self.bucket.views()

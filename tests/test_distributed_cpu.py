@@ -32,6 +32,21 @@ def _worker(rank, world, port, out_dir):
     lo, hi = ddp.shard_bounds(N, rank, world)
     g = orc.backward(x[lo:hi], dy[lo:hi], w, mu1, mu2, 0.5, need=("dw", "dmu1", "dmu2", "dsigma"))
     red = ddp.all_reduce_param_grads(*(torch.from_numpy(g[k]) for k in ("dw", "dmu1", "dmu2", "dsigma")))
+    # the same exchange through the overlapped form bench.py uses for N>1 (need-mask split, async all-reduce)
+    from dau_conv import _capi as cc
+    names = {cc.NEED_DX: "dx", cc.NEED_DW: "dw", cc.NEED_DMU1: "dmu1", cc.NEED_DMU2: "dmu2", cc.NEED_DSIGMA: "dsigma"}
+
+    def backward_fn(need_mask):
+        need = tuple(v for k, v in names.items() if need_mask & k)
+        o = orc.backward(x[lo:hi], dy[lo:hi], w, mu1, mu2, 0.5, need=need)
+        return tuple(torch.from_numpy(o[k]) if o.get(k) is not None else None for k in ("dx", "dw", "dmu1", "dmu2", "dsigma"))
+
+    ex = ddp.OverlappedBackward(w.shape, torch.device("cpu"))
+    dx_shard = ex.run(backward_fn)
+    red2 = ex.wait()
+    assert dx_shard.shape == (hi - lo, S, H, W)
+    for a, b in zip(red, red2):
+        assert torch.equal(a, b)
     if rank == 0:
         full = orc.backward(x, dy, w, mu1, mu2, 0.5, need=("dw", "dmu1", "dmu2", "dsigma"))
         np.savez(os.path.join(out_dir, "r.npz"), **{k: v.numpy() for k, v in zip(("dw", "dmu1", "dmu2", "dsigma"), red)},
