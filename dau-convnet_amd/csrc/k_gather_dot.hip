@@ -51,7 +51,9 @@ struct DotGeometry {
     int rx, ry;                 // regions per image
     int EX, EY;                 // staged error plane (positions): regions*8 + 2R + 1
     int Hp, Wp;                 // staged Xk plane (positions): regions*8
-    int GP;                     // unit pairs per (s,f)
+    int GP;                     // unit pairs per (s,f) handled by one wave (1 or 2)
+    int ngb;                    // unit blocks of 2*GP units: G > 4 is covered by several workgroups per (s-block, f-block)
+    int nbuf;                   // error tiles resident in LDS: 2 (load under compute) or 1 (R = 8: one tile fills the LDS)
     int AS;                     // input channels per wave
     int sblock;                 // input channels per workgroup
     int nfb, nsb, chunks, items;
@@ -68,18 +70,20 @@ DotGeometry make_dot_geometry(const Shape& sh, int R) {
     g.EY = g.ry * kRH + 2 * R + 1;
     g.Hp = g.ry * kRH;
     g.Wp = g.rx * kRW;
-    g.GP = (sh.G + 1) / 2;
+    g.GP = sh.G <= 2 ? 1 : 2;
+    g.ngb = (sh.G + 2 * g.GP - 1) / (2 * g.GP);
     g.AS = (getenv("DAU_DOT_AS1") && g.GP == 2) ? 1 : 2;
     g.sblock = kDWaves * g.AS;
     g.nfb = (sh.F + kDF - 1) / kDF;
     g.nsb = (sh.S + g.sblock - 1) / g.sblock;
     g.items = ((sh.N + 1) / 2) * g.rx * g.ry;
     // enough workgroups to fill the chip several times over, but no more chunks than items
-    int chunks = (256 * 4 + g.nfb * g.nsb - 1) / (g.nfb * g.nsb);
+    int chunks = (256 * 4 + g.nfb * g.nsb * g.ngb - 1) / (g.nfb * g.nsb * g.ngb);
     if (chunks > g.items) chunks = g.items;
     if (chunks < 1) chunks = 1;
     g.chunks = chunks;
     g.tile_bytes = round_up((size_t)g.erows * g.epitch * kDF * 8, 1024);
+    g.nbuf = 2 * g.tile_bytes <= 160 * 1024 ? 2 : 1;
     return g;
 }
 
@@ -191,18 +195,19 @@ __global__ void __launch_bounds__(512) blur4_pack_kernel(const float* __restrict
     }
 }
 
-// per-lane parameters: params[s][gp][fb][lane][8] = {b00, b01, b10, b11, base, 0, 0, 0}
-// lane = half*32 + fl ; unit = (s, g = 2*gp + half, f = fb*32 + fl); invalid units get zero factors.
+// per-lane parameters: params[s][gb][gp][fb][lane][8] = {b00, b01, b10, b11, base, 0, 0, 0}
+// lane = half*32 + fl ; unit = (s, g = gb*2*GP + 2*gp + half, f = fb*32 + fl); invalid units get zero factors.
 __global__ void dot_params_kernel(const UnitRef* __restrict__ table, int S, int G, int F, int R, int epitch, int GP,
-                                  int nfb, int s_pad, float* __restrict__ params) {
-    const long total = (long)s_pad * GP * nfb * 64;
+                                  int ngb, int nfb, int s_pad, float* __restrict__ params) {
+    const long total = (long)s_pad * ngb * GP * nfb * 64;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(idx % 64);
         long t = idx / 64;
         const int fb = (int)(t % nfb); t /= nfb;
-        const int gp = (int)(t % GP);
-        const int s = (int)(t / GP);
-        const int g = 2 * gp + (lane >> 5), fl = lane & 31, f = fb * kDF + fl;
+        const int gp = (int)(t % GP); t /= GP;
+        const int gb = (int)(t % ngb);
+        const int s = (int)(t / ngb);
+        const int g = gb * 2 * GP + 2 * gp + (lane >> 5), fl = lane & 31, f = fb * kDF + fl;
         UnitRef u{0, 0, 0.0f, 0.0f, 0.0f, 0.0f};
         if (s < S && g < G && f < F) u = table[((long)s * G + g) * F + f];
         const int base = (((R - u.oy) * epitch + (R - u.ox)) * kDF + fl) * 8;
@@ -230,7 +235,7 @@ struct DotArgs {
     const float* params;
     float* partial;
     int N, S, F, G, R;
-    int NP, nfb, nsb, chunks, items;
+    int NP, nfb, nsb, ngb, nbuf, chunks, items;
     int rx, ry, EX, EY, Hp, Wp, epitch, erows, s_pad;
     unsigned tile_bytes;
     int debug;   // timing experiments only (DAU_DOT_DEBUG): 1 = Xk always from one address, 2 = no error-tile refills
@@ -278,8 +283,9 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
         logical = (xcd < rem ? xcd * (chunk_ + 1) : rem * (chunk_ + 1) + (xcd - rem) * chunk_) + idx;
     }
     const int sb = logical % a.nsb;
-    const int fb = (logical / a.nsb) % a.nfb;
-    const int chunk = logical / (a.nsb * a.nfb);
+    const int gb = (logical / a.nsb) % a.ngb;
+    const int fb = (logical / (a.nsb * a.ngb)) % a.nfb;
+    const int chunk = logical / (a.nsb * a.ngb * a.nfb);
 
     // this chunk's contiguous range of items (image pair, region)
     const int per = (a.items + a.chunks - 1) / a.chunks;
@@ -296,7 +302,7 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
         s_of[si] = s;
 #pragma unroll
         for (int gp = 0; gp < GP; ++gp) {
-            const float* p = a.params + ((((long)s * GP + gp) * a.nfb + fb) * 64 + lane) * kParamDwords;
+            const float* p = a.params + (((((long)s * a.ngb + gb) * GP + gp) * a.nfb + fb) * 64 + lane) * kParamDwords;
             bw[si][gp][0] = f2{p[0], p[1]};
             bw[si][gp][1] = f2{p[2], p[3]};
             base[si][gp] = (unsigned)__float_as_int(p[4]);
@@ -355,12 +361,15 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
         for (int i = 0; i < kRW; ++i) x_load(xr[i], xlane, x0, i * 32);
     }
     for (int item = item0; item < item1; ++item) {
-        const int buf = (item - item0) & 1;
-        // the error tile of this item was requested one whole item ago: everything but the 8 newest vector
-        // memory operations (the Xk ring) has to be complete
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        const bool two = a.nbuf == 2;
+        const int buf = two ? (item - item0) & 1 : 0;
+        // Two tiles: the error tile of this item was requested one whole item ago, so everything but the 8 newest vector
+        // memory operations (the Xk ring) has to be complete.  One tile (it fills the LDS): it was requested after the
+        // previous item's last ring refill, so everything has to be complete; that load is exposed, a few us per ~100 us item.
+        if (two) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (item + 1 < item1 && !(a.debug & 2)) issue(item + 1, buf ^ 1);
+        if (two && item + 1 < item1 && !(a.debug & 2)) issue(item + 1, buf ^ 1);
         const unsigned bufoff = buf * tile_bytes;
 #pragma unroll
         for (int si = 0; si < AS; ++si) {
@@ -462,6 +471,10 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
                 for (int gp = 0; gp < GP; ++gp) { rowaddr[gp] = rowaddr2[gp]; rowaddr2[gp] += row_bytes; }
             }
         }
+        if (!two && item + 1 < item1) {
+            __syncthreads();            // every wave is done with the only tile
+            issue(item + 1, 0);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -472,7 +485,7 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
     for (int si = 0; si < AS; ++si)
 #pragma unroll
         for (int gp = 0; gp < GP; ++gp) {
-            const int s = s_of[si], g = 2 * gp + half;
+            const int s = s_of[si], g = gb * 2 * GP + 2 * gp + half;
             if (s < a.S && g < a.G && f < a.F) {
                 float* dst = a.partial + (long)chunk * kNumK * units + ((long)s * a.G + g) * a.F + f;
 #pragma unroll
@@ -497,7 +510,7 @@ DotLayout dot_layout(const TiledDotConfig& c, const DotGeometry& g) {
     size_t off = 0;
     l.ep_off = off; off += round_up(NP * g.nfb * g.EY * g.EX * kDF * 8, 256);
     l.xk_off = off; off += round_up(NP * s_pad * g.Hp * g.Wp * 32, 256);
-    l.params_off = off; off += round_up(s_pad * g.GP * g.nfb * 64 * kParamDwords * 4, 256);
+    l.params_off = off; off += round_up(s_pad * g.ngb * g.GP * g.nfb * 64 * kParamDwords * 4, 256);
     l.partial_off = off; off += round_up((size_t)g.chunks * kNumK * c.sh.S * c.sh.G * c.sh.F * 4, 256);
     l.total = off;
     return l;
@@ -527,8 +540,7 @@ void launch_dot(hipStream_t st, const DotArgs& a, int grid, size_t lds) {
 
 bool tiled_dot_configure(const Shape& sh, int R, int blur_k, TiledDotConfig* cfg) {
     const DotGeometry g = make_dot_geometry(sh, R);
-    if (g.GP > 2) return false;                                  // G <= 4 (three unit pairs per wave spill registers)
-    if (2 * g.tile_bytes > 160 * 1024) return false;             // R = 4 only for now (8x8 regions)
+    if (g.tile_bytes > 160 * 1024) return false;                 // R <= 8 (8x8 regions: (8 + 2R + 1)^2 positions of 256 B)
     // immediates of the unrolled column walk must fit 16 bits
     if ((size_t)g.epitch * kDF * 8 + (kRW + 1) * kDF * 8 > 65535) return false;
     {
@@ -572,10 +584,10 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
                            s.H, s.W, c.blur_k, g.Hp, g.Wp, band, reinterpret_cast<float*>(ws + l.xk_off));
     }
     {
-        const long total = (long)s_pad * g.GP * g.nfb * 64;
+        const long total = (long)s_pad * g.ngb * g.GP * g.nfb * 64;
         const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         hipLaunchKernelGGL(dot_params_kernel, dim3(grid), dim3(256), 0, st, table_bare, s.S, s.G, s.F, c.R, g.epitch, g.GP,
-                           g.nfb, s_pad, reinterpret_cast<float*>(ws + l.params_off));
+                           g.ngb, g.nfb, s_pad, reinterpret_cast<float*>(ws + l.params_off));
     }
 }
 
@@ -590,13 +602,13 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
     a.params = reinterpret_cast<const float*>(ws + l.params_off);
     a.partial = reinterpret_cast<float*>(ws + l.partial_off);
     a.N = s.N; a.S = s.S; a.F = s.F; a.G = s.G; a.R = c.R;
-    a.NP = c.NP; a.nfb = g.nfb; a.nsb = g.nsb; a.chunks = g.chunks; a.items = g.items;
+    a.NP = c.NP; a.nfb = g.nfb; a.nsb = g.nsb; a.ngb = g.ngb; a.nbuf = g.nbuf; a.chunks = g.chunks; a.items = g.items;
     a.rx = g.rx; a.ry = g.ry; a.EX = g.EX; a.EY = g.EY; a.Hp = g.Hp; a.Wp = g.Wp; a.epitch = g.epitch; a.erows = g.erows;
     a.s_pad = g.nsb * g.sblock;
     a.tile_bytes = (unsigned)g.tile_bytes;
     a.debug = getenv("DAU_DOT_DEBUG") ? atoi(getenv("DAU_DOT_DEBUG")) : 0;
-    const int grid = g.chunks * g.nfb * g.nsb;
-    const size_t lds = 2 * g.tile_bytes;
+    const int grid = g.chunks * g.nfb * g.ngb * g.nsb;
+    const size_t lds = (size_t)g.nbuf * g.tile_bytes;
     switch (g.GP) {
         case 1: launch_dot<1, 2>(st, a, grid, lds); break;
         case 2: if (g.AS == 2) launch_dot<2, 2>(st, a, grid, lds); else launch_dot<2, 1>(st, a, grid, lds); break;

@@ -65,6 +65,10 @@ def test_tiled_kernels_are_selected_for_benchmark_shapes():
     for (H, W, k) in ((56, 56, 9), (32, 32, 9), (32, 32, 17), (16, 16, 9), (8, 8, 9), (27, 27, 9), (28, 28, 9), (24, 24, 9)):
         info = _capi.Plan(2, 4, 8, 2, H, W, max_kernel_size=k).info
         assert info["algo_forward"] == _capi.ALGO_TILED, (H, W, k, info)
+    # gather-dot: any image size, any unit count, kernels 9 and 17
+    for (H, W, k, G) in ((56, 56, 9, 4), (27, 27, 9, 4), (65, 8, 9, 2), (32, 32, 17, 6), (56, 56, 17, 8), (100, 90, 9, 1)):
+        info = _capi.Plan(2, 4, 8, G, H, W, max_kernel_size=k).info
+        assert info["algo_backward"] == _capi.ALGO_TILED, (H, W, k, G, info)
 
 
 def test_mu_learning_rate_factor_and_need_mask():
@@ -161,6 +165,14 @@ def test_error_convention():
     dict(N=2, W=27, H=27, S=12, F=32, G=4, k=9, m=3),
     dict(N=3, W=56, H=56, S=8, F=32, G=4, k=9, m=3),
     dict(N=2, W=28, H=28, S=16, F=16, G=4, k=9, m=3),
+    # unit counts of the reference's dau_units (1x1 .. 4x2): one, odd, six and eight units per channel
+    dict(N=2, W=16, H=16, S=5, F=40, G=1, k=9, m=3),
+    dict(N=2, W=24, H=24, S=6, F=32, G=3, k=9, m=3),
+    dict(N=3, W=32, H=32, S=9, F=32, G=6, k=9, m=3),
+    dict(N=2, W=16, H=16, S=33, F=48, G=8, k=9, m=3),
+    # kernel 17 on a 56x56 map (single-tile gather-dot, R = 8 gather-sum variant) and with six units
+    dict(N=3, W=56, H=56, S=6, F=32, G=4, k=17, m=7),
+    dict(N=2, W=32, H=32, S=17, F=32, G=6, k=17, m=7),
 ])
 @pytest.mark.parametrize("algo", sorted(ALGOS))
 def test_seeded_shapes_against_c_oracle(shape, algo):
