@@ -13,8 +13,9 @@ struct TiledConfig {
     int R;            // offset bucket
     int blur_k;       // prefilter support
     int NP;           // image pairs = ceil(N/2)
-    int rows, pitch;  // staged plane: rows = H + 2R + 1, pitch (in positions) = W + 2R + 1 rounded so pitch % 32 == 8
-    int tiles_x, tiles_y;   // 8x8 position tiles covering (H+1) x (W+1)
+    int patches;      // patches per image: big or odd-sized images are gathered patch by patch
+    int rows, pitch;  // staged plane of a patch: rows = ph + 2R + 1, pitch (in positions) >= pw + 2R + 1 with pitch % 32 == 8
+    int tiles_x, tiles_y;   // 8x8 position tiles of a patch
     int fblock;       // out-channels per workgroup
     int variant;      // kernel instantiation id
 };

@@ -42,28 +42,66 @@ constexpr int kUnitDwords = 8;    // packed unit: {w00,off,w01,off,w10,offT,w11,
 
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// An image is cut into patches of ph x pw pixels; every patch is gathered by one workgroup pass from its own staged
+// plane (the patch plus a border of R on the left/top and R+1 on the right/bottom, taken from the neighbouring pixels of
+// the blurred image, zero outside it).  EDGE variants have ph = 8*ty, pw = 8*tx whatever H and W are (pixels beyond the
+// image are computed and dropped at the store); the one non-EDGE variant covers a whole 25..31 pixel image.
 struct Geometry {
-    int H, W, R;
-    int rows, pitch;          // staged plane
-    int tx, ty;               // regular 8x8 tiles
-    int edge;                 // 1: W%8==0 && H%8==0 -> separate edge tiles; 0: regular tiles cover (H+1)x(W+1)
-    int strip_pitch;          // EDGE: rows of the transposed strip (columns W .. W+2R of the plane, column-major)
+    int H, W, R;              // image, offset bucket
+    int ph, pw;               // patch (pixels)
+    int npx, npy;             // patches per image
+    int rows, pitch, cols;    // staged plane of one patch: rows x pitch positions, the first `cols` columns carry data
+    int tx, ty;               // regular 8x8 tiles of a patch
+    int edge;                 // 1: separate edge tiles for the extra row / column of Z; 0: regular tiles cover (H+1)x(W+1)
+    int variant;              // row of kVariants, -1: no instantiated kernel fits
+    int strip_pitch;          // EDGE: rows of the transposed strip (columns pw .. pw+2R of the plane, column-major)
     size_t strip_off;         // byte offset of the strip inside a staged plane
     size_t plane_bytes;       // padded to 1 KiB (one global_load_lds wave instruction)
 };
 
+struct Variant { int tx, ty, pitch, edge, split, tuning; };
+// instantiated kernels (add rows here and in the dispatch of tiled_gather_run)
+const Variant kVariants[] = {
+    {7, 7, 72, 1, 2, 0},    // 56x56 patches, R=4
+    {7, 7, 104, 1, 2, 0},   // 56x56 patches, R=8/16
+    {4, 4, 72, 1, 1, 0},    // 32x32 patches, R<=16
+    {2, 2, 40, 1, 1, 0},    // 16x16 patches, R<=8
+    {3, 3, 40, 1, 1, 0},    // 24x24 patches, R=4
+    {1, 1, 40, 1, 1, 0},    // 8x8 patches, R<=8
+    {4, 4, 40, 0, 1, 0},    // one 25..31 pixel image (27x27, 28x28), R=4
+    {7, 7, 72, 1, 3, 1},    // 56x56, R=4, three waves per output channel (tuning alternative, DAU_GATHER_SPLIT=3)
+};
+
 Geometry make_geometry(int H, int W, int R) {
     Geometry g{};
-    g.H = H; g.W = W; g.R = R;
-    g.edge = (H % 8 == 0 && W % 8 == 0) ? 1 : 0;
-    g.tx = g.edge ? W / 8 : (W + 1 + 7) / 8;
-    g.ty = g.edge ? H / 8 : (H + 1 + 7) / 8;
-    const int need_cols = (g.edge ? W + 1 : g.tx * 8) + 2 * R;
-    const int need_rows = (g.edge ? H + 1 : g.ty * 8) + 2 * R;
-    int pitch = need_cols;
-    while (pitch % 32 != 8) ++pitch;
-    g.pitch = pitch;
-    g.rows = need_rows;
+    g.H = H; g.W = W; g.R = R; g.variant = -1;
+    const char* split_env = getenv("DAU_GATHER_SPLIT");      // tuning knob: waves per output channel
+    const int want_split = split_env ? atoi(split_env) : 0;
+    double best = 0.0;
+    for (int i = 0; i < (int)(sizeof(kVariants) / sizeof(kVariants[0])); ++i) {
+        const Variant& v = kVariants[i];
+        if (v.tuning && v.split != want_split) continue;
+        int ph, pw, cols, rows;
+        if (v.edge) {
+            ph = v.ty * 8; pw = v.tx * 8;
+            cols = pw + 1 + 2 * R; rows = ph + 1 + 2 * R;
+        } else {
+            // whole image in one patch, regular tiles cover the (H+1) x (W+1) domain of Z
+            if ((W + 1 + 7) / 8 != v.tx || (H + 1 + 7) / 8 != v.ty) continue;
+            ph = H; pw = W;
+            cols = v.tx * 8 + 2 * R; rows = v.ty * 8 + 2 * R;
+        }
+        if (cols > v.pitch) continue;
+        const int npx = (W + pw - 1) / pw, npy = (H + ph - 1) / ph;
+        // relative cost of one plane pass: MFMA tiles + a fixed part (barrier, unit fetch) + the DMA of the plane
+        double cost = (double)npx * npy * (v.tx * v.ty + (v.edge ? 2 : 0) + 4 + 0.02 * rows * v.pitch / 8.0);
+        if (v.tuning) cost = 0.0;                            // explicitly requested
+        if (g.variant >= 0 && cost >= best) continue;
+        best = cost;
+        g.variant = i; g.ph = ph; g.pw = pw; g.npx = npx; g.npy = npy; g.rows = rows; g.cols = cols; g.pitch = v.pitch;
+        g.tx = v.tx; g.ty = v.ty; g.edge = v.edge;
+    }
+    if (g.variant < 0) return g;
     g.strip_pitch = g.rows;
     g.strip_off = (size_t)g.rows * g.pitch * 8;
     g.plane_bytes = round_up(g.strip_off + (g.edge ? (size_t)(2 * R + 1) * g.strip_pitch * 8 : 0), 1024);
@@ -73,33 +111,49 @@ Geometry make_geometry(int H, int W, int R) {
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-// blur + pack: in[N,C,H,W] -> staged[NP][C][rows][pitch][2] (zero border of R on the left/top,
-// >= R+1 on the right/bottom), blurred with the separable Gaussian gx (x) gy.  One workgroup per
-// (image pair, channel): raw planes -> LDS, horizontal pass -> LDS, vertical pass -> coalesced rows.
-// HBM bound: reads the NCHW input once, writes the staged copy once.
+// blur + pack: in[N,C,H,W] -> staged[NP][patch][C][rows][pitch][2].  Staged position (row, col) of patch (py, px) is the
+// blurred image at (py*ph - R + row, px*pw - R + col), zero outside the image, blurred with the separable Gaussian
+// gx (x) gy.  One workgroup per (image pair, patch, channel): raw window -> LDS, horizontal pass -> LDS, vertical pass
+// -> coalesced rows.  HBM bound: reads the NCHW input once (plus patch halos), writes the staged copy once.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(512) blur_pack_kernel(const float* __restrict__ in, const float* __restrict__ taps,
-                                                        int mirrored, int N, int C, int H, int W, int R, int k, int rows,
-                                                        int pitch, int strip_cols, size_t plane_floats,
-                                                        float* __restrict__ staged) {
+struct BlurPackArgs {
+    const float* in;
+    const float* taps;
+    float* staged;
+    int mirrored, N, C, H, W, R, k;
+    int ph, pw, npx, npy;
+    int rows, pitch, cols, strip_cols;
+    size_t plane_floats;
+};
+
+__global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int np = blockIdx.x / C, c = blockIdx.x % C;
+    const int C = a.C, H = a.H, W = a.W, R = a.R, k = a.k;
+    const int c = blockIdx.x % C;
+    const int npp = blockIdx.x / C;                // (image pair, patch)
+    const int npatch = a.npx * a.npy;
+    const int np = npp / npatch, patch = npp % npatch;
+    const int wy0 = (patch / a.npx) * a.ph - R, wx0 = (patch % a.npx) * a.pw - R;   // image coordinates of staged (0, 0)
+    // the part of the window that lies inside the image
+    const int ya0 = wy0 > 0 ? wy0 : 0, ya1 = wy0 + a.rows < H ? wy0 + a.rows : H;
+    const int xa0 = wx0 > 0 ? wx0 : 0, xa1 = wx0 + a.cols < W ? wx0 + a.cols : W;
     const int kr = (k - 1) / 2;
-    const int lw = W + 2 * kr, lh = H + 2 * kr;
-    f2* A = reinterpret_cast<f2*>(lds);          // raw, zero halo of the blur radius   [lh][lw]
-    f2* B = A + (size_t)lh * lw;                  // after the horizontal pass           [lh][W]
-    const float* gx = taps + (mirrored ? kTapGXR : kTapGX) * kTapPitch;
-    const float* gy = taps + (mirrored ? kTapGYR : kTapGY) * kTapPitch;
+    const int bw = xa1 - xa0;
+    const int lw = bw + 2 * kr, lh = (ya1 - ya0) + 2 * kr;
+    f2* A = reinterpret_cast<f2*>(lds);          // raw window, zero outside the image   [lh][lw]
+    f2* B = A + (size_t)lh * lw;                  // after the horizontal pass            [lh][bw]
+    const float* gx = a.taps + (a.mirrored ? kTapGXR : kTapGX) * kTapPitch;
+    const float* gy = a.taps + (a.mirrored ? kTapGYR : kTapGY) * kTapPitch;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int n0 = 2 * np, n1 = 2 * np + 1;
-    const float* p0 = in + ((long)n0 * C + c) * H * W;
-    const float* p1 = in + ((long)(n1 < N ? n1 : n0) * C + c) * H * W;
-    const float m1 = n1 < N ? 1.0f : 0.0f;        // odd batch: the second image of the last pair is zero
+    const float* p0 = a.in + ((long)n0 * C + c) * H * W;
+    const float* p1 = a.in + ((long)(n1 < a.N ? n1 : n0) * C + c) * H * W;
+    const float m1 = n1 < a.N ? 1.0f : 0.0f;      // odd batch: the second image of the last pair is zero
     for (int r = wave; r < lh; r += nw) {
-        const int yy = r - kr;
+        const int yy = ya0 - kr + r;
         const bool rowin = yy >= 0 && yy < H;
         for (int xl = lane; xl < lw; xl += 64) {
-            const int xx = xl - kr;
+            const int xx = xa0 - kr + xl;
             f2 v = {0.0f, 0.0f};
             if (rowin && xx >= 0 && xx < W) { v.x = p0[yy * W + xx]; v.y = m1 * p1[yy * W + xx]; }
             A[r * lw + xl] = v;
@@ -107,29 +161,30 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const float* __restrict_
     }
     __syncthreads();
     for (int r = wave; r < lh; r += nw) {
-        const bool rowin = r >= kr && r < kr + H;
-        for (int x = lane; x < W; x += 64) {
+        const int yy = ya0 - kr + r;
+        const bool rowin = yy >= 0 && yy < H;
+        for (int x = lane; x < bw; x += 64) {
             f2 acc = {0.0f, 0.0f};
             if (rowin)
                 for (int i = 0; i < k; ++i) acc = __builtin_elementwise_fma(A[r * lw + x + i], f2{gx[i], gx[i]}, acc);
-            B[r * W + x] = acc;
+            B[r * bw + x] = acc;
         }
     }
     __syncthreads();
-    f2* out = reinterpret_cast<f2*>(staged + ((size_t)np * C + c) * plane_floats);
-    f2* strip = out + (size_t)rows * pitch;
-    for (int row = wave; row < rows; row += nw) {
-        const int yy = row - R;
-        const bool rowin = yy >= 0 && yy < H;
-        for (int col = lane; col < pitch; col += 64) {
-            const int xx = col - R;
+    f2* out = reinterpret_cast<f2*>(a.staged + ((size_t)npp * C + c) * a.plane_floats);
+    f2* strip = out + (size_t)a.rows * a.pitch;
+    for (int row = wave; row < a.rows; row += nw) {
+        const int iy = wy0 + row;
+        const bool rowin = iy >= ya0 && iy < ya1;
+        for (int col = lane; col < a.pitch; col += 64) {
+            const int ix = wx0 + col;
             f2 acc = {0.0f, 0.0f};
-            if (rowin && xx >= 0 && xx < W)
-                for (int j = 0; j < k; ++j) acc = __builtin_elementwise_fma(B[(yy + j) * W + xx], f2{gy[j], gy[j]}, acc);
-            out[row * pitch + col] = acc;
-            // columns W .. W+2R are stored a second time column-major: the edge-column tile of the gather reads a
+            if (rowin && ix >= xa0 && ix < xa1)
+                for (int j = 0; j < k; ++j) acc = __builtin_elementwise_fma(B[(iy - ya0 + j) * bw + (ix - xa0)], f2{gy[j], gy[j]}, acc);
+            out[row * a.pitch + col] = acc;
+            // columns pw .. pw+2R are stored a second time column-major: the edge-column tile of the gather reads a
             // vertical run of positions, which is bank-conflict free only in this orientation
-            if (strip_cols > 0 && col >= W && col < W + strip_cols) strip[(col - W) * rows + row] = acc;
+            if (a.strip_cols > 0 && col >= a.pw && col < a.pw + a.strip_cols) strip[(col - a.pw) * a.rows + row] = acc;
         }
     }
 }
@@ -167,6 +222,7 @@ struct GatherArgs {
     const char* packed;        // [NFB][Cin][ut_stride]
     float* out;                // [N][Cout][H][W]
     int N, Cin, Cout, G, H, W, R;
+    int npx, npy;              // patches per image (EDGE variants: 8*TY x 8*TX pixels each)
     int nfb;                   // ceil(Cout / kFB)
     unsigned plane_bytes, ut_stride;
     unsigned strip_off;        // byte offset of the transposed strip inside a plane
@@ -303,9 +359,13 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
         const int chunk = nblk / 8, rem = nblk % 8;
         logical = (xcd < rem ? xcd * (chunk + 1) : rem * (chunk + 1) + (xcd - rem) * chunk) + idx;
     }
-    const int np = logical / a.nfb, fb = logical % a.nfb;
+    const int npp = logical / a.nfb, fb = logical % a.nfb;      // (image pair, patch), channel block
+    const int npatch = a.npx * a.npy;
+    const int np = npp / npatch, patch = npp % npatch;
+    const int y0 = (patch / a.npx) * (TY * 8), x0 = (patch % a.npx) * (TX * 8);   // patch origin (0 for the non-EDGE variant)
 
-    const int R = a.R, H = a.H, W = a.W;
+    // H, W: the domain this workgroup computes (a patch; the whole image for the non-EDGE variant)
+    const int R = a.R, H = EDGE ? TY * 8 : a.H, W = EDGE ? TX * 8 : a.W;
     const int ly = lane >> 3, lx = lane & 7;
     const unsigned lane_base = (unsigned)(((ly + R) * PITCH + (lx + R)) * 8);
     // Edge tiles (the extra row / column of Z): tile E0 = the row y = H, x = 0..W-1, read from the plane (consecutive
@@ -322,7 +382,7 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
     const unsigned ebase1 = (unsigned)(a.strip_off + (ey[1] + R) * 8);
 
     const unsigned plane_bytes = a.plane_bytes, ut_stride = a.ut_stride;
-    const char* src_planes = a.staged + (size_t)np * a.Cin * plane_bytes;
+    const char* src_planes = a.staged + (size_t)npp * a.Cin * plane_bytes;
     const char* src_units = a.packed + (size_t)fb * a.Cin * ut_stride;
     const unsigned ut_base = 2 * plane_bytes;
 
@@ -365,7 +425,8 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
     const unsigned zpitch = a.zpitch;
     const unsigned zplane = (unsigned)(H + 1) * zpitch;       // floats per tap plane
     float* zs = reinterpret_cast<float*>(smem);
-    const long HW = (long)H * W;
+    const int HW = H * W;
+    const long plane_out = (long)a.H * a.W;
 #pragma unroll
     for (int img = 0; img < 2; ++img) {   // unrolled: acc[i][img] must be a static register index
 #pragma unroll 1
@@ -391,13 +452,14 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
             }
             __syncthreads();
             const int n = 2 * np + img;
-            for (long o = threadIdx.x; o < (long)T::kEpiF * HW; o += T::kThreads) {
-                const int fl = (int)(o / HW);
-                const int p = (int)(o % HW), y = p / W, x = p % W;
+            for (int o = threadIdx.x; o < T::kEpiF * HW; o += T::kThreads) {
+                const int fl = o / HW;
+                const int p = o % HW, y = p / W, x = p % W;
                 const int f = fb * kFB + fh * T::kEpiF + fl;
                 const float* zf = zs + (size_t)fl * 4 * zplane + (unsigned)y * zpitch + x;
                 const float v = zf[0] + zf[zplane + 1] + zf[2 * zplane + zpitch] + zf[3 * zplane + zpitch + 1];
-                if (n < a.N && f < a.Cout) a.out[((long)n * a.Cout + f) * HW + p] = v;
+                if (n < a.N && f < a.Cout && y0 + y < a.H && x0 + x < a.W)
+                    a.out[((long)n * a.Cout + f) * plane_out + (long)(y0 + y) * a.W + (x0 + x)] = v;
             }
         }
     }
@@ -420,19 +482,6 @@ __global__ void __launch_bounds__(kFB * SPLIT * 64) gather_mfma_kernel(const Gat
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-struct Variant { int tx, ty, pitch, edge, split; };
-// instantiated geometries (add rows here and in dispatch below)
-const Variant kVariants[] = {
-    {7, 7, 72, 1, 2},    // 56x56, R=4
-    {7, 7, 104, 1, 2},   // 56x56, R=8/16
-    {4, 4, 72, 1, 1},    // 32x32
-    {2, 2, 40, 1, 1},    // 16x16
-    {3, 3, 40, 1, 1},    // 24x24
-    {1, 1, 40, 1, 1},    // 8x8
-    {4, 4, 40, 0, 1},    // 25..31 square-ish (27x27, 28x28), R=4
-    {7, 7, 72, 1, 3},    // 56x56, R=4, three waves per output channel (tuning alternative, DAU_GATHER_SPLIT=3)
-};
-
 template <int TX, int TY, int PITCH, bool EDGE, int SPLIT>
 void launch_variant(hipStream_t st, const GatherArgs& a, int grid, size_t lds) {
     using T = GatherTraits<TX, TY, PITCH, EDGE, SPLIT>;
@@ -445,16 +494,18 @@ void launch_variant(hipStream_t st, const GatherArgs& a, int grid, size_t lds) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T::kThreads), lds, st, a);
 }
 
-size_t blur_pack_lds_bytes(int H, int W, int k) {
-    return ((size_t)(H + k - 1) * (W + k - 1) + (size_t)(H + k - 1) * W) * 8;
+// largest window any patch needs: raw [lh][lw] + horizontally filtered [lh][bw]
+size_t blur_pack_lds_bytes(const Geometry& g, int k) {
+    const size_t wh = g.rows < g.H ? g.rows : g.H, ww = g.cols < g.W ? g.cols : g.W;
+    return ((wh + k - 1) * (ww + k - 1) + (wh + k - 1) * ww) * 8;
 }
 
 size_t ut_stride_bytes(int G) { return round_up((size_t)G * kFB * kUnitDwords * 4, 1024); }
 
 size_t lds_bytes(const TiledConfig& c, const Geometry& g) {
     const size_t main_b = 2 * g.plane_bytes + 2 * ut_stride_bytes(c.G);
-    const size_t zpitch = c.W + 2;
-    const size_t epi_b = (size_t)2 /*kEpiF*/ * 4 * (c.H + 1) * zpitch * 4;
+    const size_t zpitch = g.pw + 2;
+    const size_t epi_b = (size_t)2 /*kEpiF*/ * 4 * (g.ph + 1) * zpitch * 4;
     return main_b > epi_b ? main_b : epi_b;
 }
 
@@ -462,23 +513,15 @@ size_t lds_bytes(const TiledConfig& c, const Geometry& g) {
 
 bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, TiledConfig* cfg) {
     const Geometry g = make_geometry(H, W, R);
-    int variant = -1;
-    const char* split_env = getenv("DAU_GATHER_SPLIT");      // tuning knob: waves per output channel
-    const int want_split = split_env ? atoi(split_env) : 0;
-    for (size_t i = 0; i < sizeof(kVariants) / sizeof(kVariants[0]); ++i)
-        if (kVariants[i].tx == g.tx && kVariants[i].ty == g.ty && kVariants[i].pitch == g.pitch && kVariants[i].edge == g.edge &&
-            (want_split == 0 || kVariants[i].split == want_split || variant < 0)) {
-            if (variant < 0 || kVariants[i].split == want_split) variant = (int)i;
-            if (want_split == 0) break;
-        }
-    if (variant < 0) return false;
+    if (g.variant < 0) return false;
     TiledConfig c{};
     c.N = N; c.Cin = Cin; c.Cout = Cout; c.G = G; c.H = H; c.W = W; c.R = R; c.blur_k = blur_k;
     c.NP = (N + 1) / 2;
-    c.rows = g.rows; c.pitch = g.pitch; c.tiles_x = g.tx; c.tiles_y = g.ty; c.fblock = kFB; c.variant = variant;
+    c.rows = g.rows; c.pitch = g.pitch; c.tiles_x = g.tx; c.tiles_y = g.ty; c.fblock = kFB; c.variant = g.variant;
+    c.patches = g.npx * g.npy;
     if (lds_bytes(c, g) > 160 * 1024) return false;
     // blur_pack keeps both raw planes (+ blur halo) and the horizontally filtered rows in LDS
-    if (blur_pack_lds_bytes(H, W, blur_k) > 150 * 1024) return false;
+    if (blur_pack_lds_bytes(g, blur_k) > 150 * 1024) return false;
     *cfg = c;
     return true;
 }
@@ -486,23 +529,27 @@ bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R
 size_t tiled_gather_workspace_bytes(const TiledConfig& c) {
     const Geometry g = make_geometry(c.H, c.W, c.R);
     const size_t nfb = (c.Cout + kFB - 1) / kFB;
-    return round_up((size_t)c.NP * c.Cin * g.plane_bytes, 256) + round_up(nfb * c.Cin * ut_stride_bytes(c.G), 256);
+    return round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256) + round_up(nfb * c.Cin * ut_stride_bytes(c.G), 256);
 }
 
 void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in, const float* filters, bool mirrored,
                           const UnitRef* table, void* workspace) {
     const Geometry g = make_geometry(c.H, c.W, c.R);
     char* staged = static_cast<char*>(workspace);
-    char* packed = staged + round_up((size_t)c.NP * c.Cin * g.plane_bytes, 256);
-    const size_t blur_lds = blur_pack_lds_bytes(c.H, c.W, c.blur_k);
+    char* packed = staged + round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256);
+    const size_t blur_lds = blur_pack_lds_bytes(g, c.blur_k);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blur_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(blur_pack_kernel, dim3(c.NP * c.Cin), dim3(512), blur_lds, st, in, filters + kTaps1dOffset, mirrored ? 1 : 0,
-                       c.N, c.Cin, c.H, c.W, c.R, c.blur_k, g.rows, g.pitch, g.edge ? 2 * c.R + 1 : 0, g.plane_bytes / 4,
-                       reinterpret_cast<float*>(staged));
+    BlurPackArgs b{};
+    b.in = in; b.taps = filters + kTaps1dOffset; b.staged = reinterpret_cast<float*>(staged);
+    b.mirrored = mirrored ? 1 : 0; b.N = c.N; b.C = c.Cin; b.H = c.H; b.W = c.W; b.R = c.R; b.k = c.blur_k;
+    b.ph = g.ph; b.pw = g.pw; b.npx = g.npx; b.npy = g.npy;
+    b.rows = g.rows; b.pitch = g.pitch; b.cols = g.cols; b.strip_cols = g.edge ? 2 * c.R + 1 : 0;
+    b.plane_floats = g.plane_bytes / 4;
+    hipLaunchKernelGGL(blur_pack_kernel, dim3(c.NP * c.patches * c.Cin), dim3(512), blur_lds, st, b);
     const int nfb = (c.Cout + kFB - 1) / kFB;
     const size_t uts = ut_stride_bytes(c.G);
     // packed slices are padded to whole KiB; zero the padding once per call together with the payload
@@ -518,16 +565,17 @@ void tiled_gather_run(hipStream_t st, const TiledConfig& c, float* out, void* wo
     const Geometry g = make_geometry(c.H, c.W, c.R);
     GatherArgs a{};
     a.staged = static_cast<const char*>(workspace);
-    a.packed = a.staged + round_up((size_t)c.NP * c.Cin * g.plane_bytes, 256);
+    a.packed = a.staged + round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256);
     a.out = out;
+    a.npx = g.npx; a.npy = g.npy;
     a.N = c.N; a.Cin = c.Cin; a.Cout = c.Cout; a.G = c.G; a.H = c.H; a.W = c.W; a.R = c.R;
     a.nfb = (c.Cout + kFB - 1) / kFB;
     a.plane_bytes = (unsigned)g.plane_bytes;
     a.strip_off = (unsigned)g.strip_off;
     a.ut_stride = (unsigned)ut_stride_bytes(c.G);
-    a.zpitch = (unsigned)(c.W + 2);
+    a.zpitch = (unsigned)(g.pw + 2);
     a.debug = getenv("DAU_GATHER_DEBUG") ? atoi(getenv("DAU_GATHER_DEBUG")) : 0;
-    const int grid = c.NP * a.nfb;
+    const int grid = c.NP * c.patches * a.nfb;
     const size_t lds = lds_bytes(c, g);
     switch (c.variant) {
         case 0: launch_variant<7, 7, 72, true, 2>(st, a, grid, lds); break;

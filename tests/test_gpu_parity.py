@@ -62,7 +62,10 @@ def test_golden_vectors(name, algo):
 def test_tiled_kernels_are_selected_for_benchmark_shapes():
     """AUTO must pick the LDS-tiled MFMA gather for the shapes the benchmark runs (no silent slow path)."""
     from dau_conv import _capi
-    for (H, W, k) in ((56, 56, 9), (32, 32, 9), (32, 32, 17), (16, 16, 9), (8, 8, 9), (27, 27, 9), (28, 28, 9), (24, 24, 9)):
+    for (H, W, k) in ((56, 56, 9), (32, 32, 9), (32, 32, 17), (16, 16, 9), (8, 8, 9), (27, 27, 9), (28, 28, 9), (24, 24, 9),
+                      # patch decomposition: feature maps of ResNet / CIFAR stages, odd sizes, large images, kernels 17 and 33
+                      (14, 14, 9), (7, 7, 9), (64, 64, 9), (112, 112, 9), (8, 65, 9), (90, 100, 9), (224, 224, 9), (56, 56, 17),
+                      (64, 64, 33), (128, 96, 17)):
         info = _capi.Plan(2, 4, 8, 2, H, W, max_kernel_size=k).info
         assert info["algo_forward"] == _capi.ALGO_TILED, (H, W, k, info)
     # gather-dot: any image size, any unit count, kernels 9 and 17
@@ -165,6 +168,13 @@ def test_error_convention():
     dict(N=2, W=27, H=27, S=12, F=32, G=4, k=9, m=3),
     dict(N=3, W=56, H=56, S=8, F=32, G=4, k=9, m=3),
     dict(N=2, W=28, H=28, S=16, F=16, G=4, k=9, m=3),
+    # patch decomposition of the tiled gather: 2x2 patches of 32 and of 56, odd sizes, one ragged patch row
+    dict(N=3, W=64, H=64, S=5, F=12, G=4, k=9, m=3),
+    dict(N=2, W=112, H=112, S=3, F=8, G=2, k=9, m=3),
+    dict(N=2, W=50, H=40, S=4, F=8, G=4, k=9, m=3),
+    dict(N=3, W=14, H=14, S=8, F=16, G=4, k=9, m=3),
+    dict(N=5, W=7, H=7, S=8, F=16, G=2, k=9, m=3),
+    dict(N=2, W=75, H=33, S=3, F=8, G=2, k=17, m=7),
     # unit counts of the reference's dau_units (1x1 .. 4x2): one, odd, six and eight units per channel
     dict(N=2, W=16, H=16, S=5, F=40, G=1, k=9, m=3),
     dict(N=2, W=24, H=24, S=6, F=32, G=3, k=9, m=3),
