@@ -36,6 +36,15 @@ WORKLOADS = {
     # AlexNet-DAU conv2 shape (configs[1])
     "c1": dict(N=64, S=96, F=256, H=27, W=27, G=4, k=9, m=3.0,
                label="AlexNet-DAU conv2 N=64/GPU C=96->256 HW=27 G=4 k=9 fp32 fwd+bwd"),
+    # configs[2] at fp32 (bf16 is not implemented): six units per channel
+    "c2": dict(N=128, S=256, F=256, H=56, W=56, G=6, k=9, m=3.0,
+               label="ResNet-50-DAU layer N=128/GPU C=256->256 HW=56 G=6 k=9 fp32 fwd+bwd"),
+    # configs[3]: per-GPU share of the N=1024 batch-sharded step
+    "c3": dict(N=128, S=512, F=512, H=28, W=28, G=4, k=9, m=3.0,
+               label="batch-sharded step N=128/GPU C=512->512 HW=28 G=4 k=9 fp32 fwd+bwd"),
+    # configs[4]: segmentation-scale maps, nine units, offsets up to +-16 (max_kernel_size 33)
+    "c4": dict(N=16, S=256, F=256, H=512, W=512, G=9, k=33, m=15.0,
+               label="seg-scale N=16/GPU C=256->256 HW=512 G=9 k=33 mu~U(-15,15) fp32 fwd+bwd"),
     "small": dict(N=8, S=32, F=32, H=56, W=56, G=4, k=9, m=3.0, label="smoke-size N=8 C=32->32 HW=56 G=4"),
 }
 FP32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak

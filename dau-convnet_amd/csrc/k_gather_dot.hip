@@ -54,6 +54,9 @@ struct DotGeometry {
     int GP;                     // unit pairs per (s,f) handled by one wave (1 or 2)
     int ngb;                    // unit blocks of 2*GP units: G > 4 is covered by several workgroups per (s-block, f-block)
     int nbuf;                   // error tiles resident in LDS: 2 (load under compute) or 1 (R = 8: one tile fills the LDS)
+    int Rt;                     // offset radius one LDS tile covers: min(R, 8)
+    int nsub1;                  // R > 8: the offset range is cut into nsub1 x nsub1 windows of radius Rt; one workgroup
+                                // pass per window, units outside the window contribute zero (their factors are zeroed)
     int AS;                     // input channels per wave
     int sblock;                 // input channels per workgroup
     int nfb, nsb, chunks, items;
@@ -62,8 +65,10 @@ struct DotGeometry {
 
 DotGeometry make_dot_geometry(const Shape& sh, int R) {
     DotGeometry g{};
-    g.epitch = kRW + 2 * R + 1;
-    g.erows = kRH + 2 * R + 1;
+    g.Rt = R < 8 ? R : 8;
+    g.nsub1 = R / g.Rt;
+    g.epitch = kRW + 2 * g.Rt + 1;
+    g.erows = kRH + 2 * g.Rt + 1;
     g.rx = (sh.W + kRW - 1) / kRW;
     g.ry = (sh.H + kRH - 1) / kRH;
     g.EX = g.rx * kRW + 2 * R + 1;
@@ -78,7 +83,8 @@ DotGeometry make_dot_geometry(const Shape& sh, int R) {
     g.nsb = (sh.S + g.sblock - 1) / g.sblock;
     g.items = ((sh.N + 1) / 2) * g.rx * g.ry;
     // enough workgroups to fill the chip several times over, but no more chunks than items
-    int chunks = (256 * 4 + g.nfb * g.nsb * g.ngb - 1) / (g.nfb * g.nsb * g.ngb);
+    const int per_chunk = g.nfb * g.nsb * g.ngb * g.nsub1 * g.nsub1;
+    int chunks = (256 * 4 + per_chunk - 1) / per_chunk;
     if (chunks > g.items) chunks = g.items;
     if (chunks < 1) chunks = 1;
     g.chunks = chunks;
@@ -125,92 +131,107 @@ __global__ void __launch_bounds__(256) pack_error_kernel(const float* __restrict
 }
 
 // x[N,S,H,W] -> XK[NP][S][Hp][Wp][4][2]: the four derivative-filtered copies (separable form, see dau_common.hpp),
-// zero padded to whole regions.  One workgroup per (pair, channel); raw planes in LDS, then bands of rows:
+// zero padded to whole regions.  One workgroup per (pair, output window, channel): raw window (+ blur halo) -> LDS,
 // three horizontal passes (gx, ax, cx) -> LDS, five vertical 1-D passes -> 32 B per position.  HBM bound.
-__global__ void __launch_bounds__(512) blur4_pack_kernel(const float* __restrict__ in, const float* __restrict__ taps,
-                                                         int N, int C, int cstride, int H, int W, int k, int Hp, int Wp,
-                                                         int band, float* __restrict__ xk) {
+struct Blur4Args {
+    const float* in;
+    const float* taps;
+    float* xk;
+    int N, C, cstride, H, W, k, Hp, Wp;
+    int WY, WX, nwy, nwx;       // output window (rows x columns of the Hp x Wp plane) and windows per plane
+};
+
+__global__ void __launch_bounds__(512) blur4_pack_kernel(const Blur4Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int np = blockIdx.x / C, c = blockIdx.x % C;
+    const int C = a.C, H = a.H, W = a.W, k = a.k;
+    int t = blockIdx.x;
+    const int c = t % C; t /= C;
+    const int wx = t % a.nwx; t /= a.nwx;
+    const int wy = t % a.nwy;
+    const int np = t / a.nwy;
+    const int oy0 = wy * a.WY, ox0 = wx * a.WX;
+    const int oh = oy0 + a.WY < a.Hp ? a.WY : a.Hp - oy0, ow = ox0 + a.WX < a.Wp ? a.WX : a.Wp - ox0;
     const int kr = (k - 1) / 2;
-    const int lw = W + 2 * kr, lh = H + 2 * kr;
-    const int bh = band + 2 * kr;                            // rows of horizontally filtered data per band
-    f2* A = reinterpret_cast<f2*>(lds);                      // raw [lh][lw]
-    f2* B = A + (size_t)lh * lw;                             // [3][bh][W]
-    const float* gx = taps + kTapGX * kTapPitch; const float* gy = taps + kTapGY * kTapPitch;
-    const float* ax = taps + kTapAX * kTapPitch; const float* ay = taps + kTapAY * kTapPitch;
-    const float* cx = taps + kTapCX * kTapPitch; const float* by = taps + kTapBY * kTapPitch;
+    const int lw = ow + 2 * kr, lh = oh + 2 * kr;
+    f2* A = reinterpret_cast<f2*>(lds);                      // raw [lh][lw], image (oy0 - kr + r, ox0 - kr + xl)
+    f2* B = A + (size_t)lh * lw;                             // [3][lh][ow]
+    const float* gx = a.taps + kTapGX * kTapPitch; const float* gy = a.taps + kTapGY * kTapPitch;
+    const float* ax = a.taps + kTapAX * kTapPitch; const float* ay = a.taps + kTapAY * kTapPitch;
+    const float* cx = a.taps + kTapCX * kTapPitch; const float* by = a.taps + kTapBY * kTapPitch;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int n0 = 2 * np, n1 = 2 * np + 1;
-    const float* p0 = in + ((long)n0 * C + c) * H * W;
-    const float* p1 = in + ((long)(n1 < N ? n1 : n0) * C + c) * H * W;
-    const float m1 = n1 < N ? 1.0f : 0.0f;
+    const float* p0 = a.in + ((long)n0 * C + c) * H * W;
+    const float* p1 = a.in + ((long)(n1 < a.N ? n1 : n0) * C + c) * H * W;
+    const float m1 = n1 < a.N ? 1.0f : 0.0f;
     for (int r = wave; r < lh; r += nw) {
-        const int yy = r - kr;
+        const int yy = oy0 - kr + r;
         const bool rowin = yy >= 0 && yy < H;
         for (int xl = lane; xl < lw; xl += 64) {
-            const int xx = xl - kr;
+            const int xx = ox0 - kr + xl;
             f2 v = {0.0f, 0.0f};
             if (rowin && xx >= 0 && xx < W) { v.x = p0[yy * W + xx]; v.y = m1 * p1[yy * W + xx]; }
             A[r * lw + xl] = v;
         }
     }
-    f8* out = reinterpret_cast<f8*>(xk) + ((size_t)np * cstride + c) * Hp * Wp;
-    for (int y0 = 0; y0 < Hp; y0 += band) {
-        __syncthreads();
-        // horizontal passes for LDS rows y0 .. y0+bh-1 (image rows y0-kr ..)
-        for (int rr = wave; rr < bh; rr += nw) {
-            const int r = y0 + rr;                          // row of A
-            const bool rowin = r >= kr && r < kr + H;
-            for (int x = lane; x < W; x += 64) {
-                f2 h1 = {0.0f, 0.0f}, h2 = {0.0f, 0.0f}, h3 = {0.0f, 0.0f};
-                if (rowin)
-                    for (int i = 0; i < k; ++i) {
-                        const f2 v = A[r * lw + x + i];
-                        h1 = __builtin_elementwise_fma(v, f2{gx[i], gx[i]}, h1);
-                        h2 = __builtin_elementwise_fma(v, f2{ax[i], ax[i]}, h2);
-                        h3 = __builtin_elementwise_fma(v, f2{cx[i], cx[i]}, h3);
-                    }
-                B[(0 * bh + rr) * W + x] = h1; B[(1 * bh + rr) * W + x] = h2; B[(2 * bh + rr) * W + x] = h3;
-            }
+    __syncthreads();
+    for (int r = wave; r < lh; r += nw) {
+        const int yy = oy0 - kr + r;
+        const bool rowin = yy >= 0 && yy < H;
+        for (int x = lane; x < ow; x += 64) {
+            f2 h1 = {0.0f, 0.0f}, h2 = {0.0f, 0.0f}, h3 = {0.0f, 0.0f};
+            if (rowin)
+                for (int i = 0; i < k; ++i) {
+                    const f2 v = A[r * lw + x + i];
+                    h1 = __builtin_elementwise_fma(v, f2{gx[i], gx[i]}, h1);
+                    h2 = __builtin_elementwise_fma(v, f2{ax[i], ax[i]}, h2);
+                    h3 = __builtin_elementwise_fma(v, f2{cx[i], cx[i]}, h3);
+                }
+            B[(0 * lh + r) * ow + x] = h1; B[(1 * lh + r) * ow + x] = h2; B[(2 * lh + r) * ow + x] = h3;
         }
-        __syncthreads();
-        for (int yr = wave; yr < band; yr += nw) {
-            const int yy = y0 + yr;
-            if (yy >= Hp) break;
-            for (int xx = lane; xx < Wp; xx += 64) {
-                f2 dw = {0.0f, 0.0f}, d1 = {0.0f, 0.0f}, d2 = {0.0f, 0.0f}, ds = {0.0f, 0.0f};
-                if (yy < H && xx < W)
-                    for (int j = 0; j < k; ++j) {
-                        const f2 b1 = B[(0 * bh + yr + j) * W + xx], b2 = B[(1 * bh + yr + j) * W + xx], b3 = B[(2 * bh + yr + j) * W + xx];
-                        dw = __builtin_elementwise_fma(b1, f2{gy[j], gy[j]}, dw);
-                        d1 = __builtin_elementwise_fma(b2, f2{gy[j], gy[j]}, d1);
-                        d2 = __builtin_elementwise_fma(b1, f2{ay[j], ay[j]}, d2);
-                        ds = __builtin_elementwise_fma(b3, f2{gy[j], gy[j]}, ds);
-                        ds = __builtin_elementwise_fma(b1, f2{by[j], by[j]}, ds);
-                    }
-                out[(size_t)yy * Wp + xx] = f8{dw.x, dw.y, d1.x, d1.y, d2.x, d2.y, ds.x, ds.y};
-            }
+    }
+    __syncthreads();
+    f8* out = reinterpret_cast<f8*>(a.xk) + ((size_t)np * a.cstride + c) * a.Hp * a.Wp;
+    for (int yr = wave; yr < oh; yr += nw) {
+        const int yy = oy0 + yr;
+        for (int xc = lane; xc < ow; xc += 64) {
+            const int xx = ox0 + xc;
+            f2 dw = {0.0f, 0.0f}, d1 = {0.0f, 0.0f}, d2 = {0.0f, 0.0f}, ds = {0.0f, 0.0f};
+            if (yy < H && xx < W)
+                for (int j = 0; j < k; ++j) {
+                    const f2 b1 = B[(0 * lh + yr + j) * ow + xc], b2 = B[(1 * lh + yr + j) * ow + xc], b3 = B[(2 * lh + yr + j) * ow + xc];
+                    dw = __builtin_elementwise_fma(b1, f2{gy[j], gy[j]}, dw);
+                    d1 = __builtin_elementwise_fma(b2, f2{gy[j], gy[j]}, d1);
+                    d2 = __builtin_elementwise_fma(b1, f2{ay[j], ay[j]}, d2);
+                    ds = __builtin_elementwise_fma(b3, f2{gy[j], gy[j]}, ds);
+                    ds = __builtin_elementwise_fma(b1, f2{by[j], by[j]}, ds);
+                }
+            out[(size_t)yy * a.Wp + xx] = f8{dw.x, dw.y, d1.x, d1.y, d2.x, d2.y, ds.x, ds.y};
         }
     }
 }
 
-// per-lane parameters: params[s][gb][gp][fb][lane][8] = {b00, b01, b10, b11, base, 0, 0, 0}
+// per-lane parameters: params[sub][s][gb][gp][fb][lane][8] = {b00, b01, b10, b11, base, 0, 0, 0}
 // lane = half*32 + fl ; unit = (s, g = gb*2*GP + 2*gp + half, f = fb*32 + fl); invalid units get zero factors.
-__global__ void dot_params_kernel(const UnitRef* __restrict__ table, int S, int G, int F, int R, int epitch, int GP,
-                                  int ngb, int nfb, int s_pad, float* __restrict__ params) {
-    const long total = (long)s_pad * ngb * GP * nfb * 64;
+__global__ void dot_params_kernel(const UnitRef* __restrict__ table, int S, int G, int F, int R, int Rt, int nsub1,
+                                  int epitch, int GP, int ngb, int nfb, int s_pad, float* __restrict__ params) {
+    const long total = (long)nsub1 * nsub1 * s_pad * ngb * GP * nfb * 64;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(idx % 64);
         long t = idx / 64;
         const int fb = (int)(t % nfb); t /= nfb;
         const int gp = (int)(t % GP); t /= GP;
-        const int gb = (int)(t % ngb);
-        const int s = (int)(t / ngb);
+        const int gb = (int)(t % ngb); t /= ngb;
+        const int s = (int)(t % s_pad);
+        const int sub = (int)(t / s_pad);
         const int g = gb * 2 * GP + 2 * gp + (lane >> 5), fl = lane & 31, f = fb * kDF + fl;
         UnitRef u{0, 0, 0.0f, 0.0f, 0.0f, 0.0f};
         if (s < S && g < G && f < F) u = table[((long)s * G + g) * F + f];
-        const int base = (((R - u.oy) * epitch + (R - u.ox)) * kDF + fl) * 8;
+        // offset window of this pass: centre c = -R + Rt + 2*Rt*i per axis; a unit belongs to exactly one window
+        int wy = (u.oy + R) / (2 * Rt), wx = (u.ox + R) / (2 * Rt);
+        wy = wy < nsub1 ? wy : nsub1 - 1; wx = wx < nsub1 ? wx : nsub1 - 1;
+        const int cy = -R + Rt + 2 * Rt * (sub / nsub1), cx = -R + Rt + 2 * Rt * (sub % nsub1);
+        if (wy != sub / nsub1 || wx != sub % nsub1) u = UnitRef{cx, cy, 0.0f, 0.0f, 0.0f, 0.0f};
+        const int base = (((Rt - (u.oy - cy)) * epitch + (Rt - (u.ox - cx))) * kDF + fl) * 8;
         float* dst = params + idx * kParamDwords;
         dst[0] = u.w00; dst[1] = u.w01; dst[2] = u.w10; dst[3] = u.w11;
         dst[4] = __int_as_float(base); dst[5] = 0.0f; dst[6] = 0.0f; dst[7] = 0.0f;
@@ -236,6 +257,7 @@ struct DotArgs {
     float* partial;
     int N, S, F, G, R;
     int NP, nfb, nsb, ngb, nbuf, chunks, items;
+    int Rt, nsub1;
     int rx, ry, EX, EY, Hp, Wp, epitch, erows, s_pad;
     unsigned tile_bytes;
     int debug;   // timing experiments only (DAU_DOT_DEBUG): 1 = Xk always from one address, 2 = no error-tile refills
@@ -285,7 +307,11 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
     const int sb = logical % a.nsb;
     const int gb = (logical / a.nsb) % a.ngb;
     const int fb = (logical / (a.nsb * a.ngb)) % a.nfb;
-    const int chunk = logical / (a.nsb * a.ngb * a.nfb);
+    const int nsub = a.nsub1 * a.nsub1;
+    const int sub = (logical / (a.nsb * a.ngb * a.nfb)) % nsub;
+    const int chunk = logical / (a.nsb * a.ngb * a.nfb * nsub);
+    // tile origin of this pass's offset window inside the staged error plane (0 when one tile covers the bucket)
+    const int sub_dy = 2 * (a.R - a.Rt) - 2 * a.Rt * (sub / a.nsub1), sub_dx = 2 * (a.R - a.Rt) - 2 * a.Rt * (sub % a.nsub1);
 
     // this chunk's contiguous range of items (image pair, region)
     const int per = (a.items + a.chunks - 1) / a.chunks;
@@ -302,7 +328,7 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
         s_of[si] = s;
 #pragma unroll
         for (int gp = 0; gp < GP; ++gp) {
-            const float* p = a.params + (((((long)s * a.ngb + gb) * GP + gp) * a.nfb + fb) * 64 + lane) * kParamDwords;
+            const float* p = a.params + ((((((long)sub * a.s_pad + s) * a.ngb + gb) * GP + gp) * a.nfb + fb) * 64 + lane) * kParamDwords;
             bw[si][gp][0] = f2{p[0], p[1]};
             bw[si][gp][1] = f2{p[2], p[3]};
             base[si][gp] = (unsigned)__float_as_int(p[4]);
@@ -322,7 +348,7 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
     auto issue = [&](int item, int buf) {
         const int np = item / regions, reg = item % regions;
         const int ry = reg / a.rx, rx = reg % a.rx;
-        const char* src = a.ep + ((((size_t)np * a.nfb + fb) * a.EY + (size_t)ry * kRH) * a.EX + (size_t)rx * kRW) * (kDF * 8);
+        const char* src = a.ep + ((((size_t)np * a.nfb + fb) * a.EY + (size_t)(ry * kRH + sub_dy)) * a.EX + (size_t)(rx * kRW + sub_dx)) * (kDF * 8);
         const unsigned pieces = tile_bytes >> 10;
         for (unsigned piece = wave; piece < pieces; piece += kDWaves) {
             const unsigned b = piece * 1024 + lane * 16;
@@ -487,7 +513,7 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
         for (int gp = 0; gp < GP; ++gp) {
             const int s = s_of[si], g = gb * 2 * GP + 2 * gp + half;
             if (s < a.S && g < a.G && f < a.F) {
-                float* dst = a.partial + (long)chunk * kNumK * units + ((long)s * a.G + g) * a.F + f;
+                float* dst = a.partial + ((long)chunk * nsub + sub) * kNumK * units + ((long)s * a.G + g) * a.F + f;
 #pragma unroll
                 for (int kk = 0; kk < kNumK; ++kk) dst[kk * units] = acc[si][gp][0][kk] + acc[si][gp][1][kk];
             }
@@ -510,19 +536,21 @@ DotLayout dot_layout(const TiledDotConfig& c, const DotGeometry& g) {
     size_t off = 0;
     l.ep_off = off; off += round_up(NP * g.nfb * g.EY * g.EX * kDF * 8, 256);
     l.xk_off = off; off += round_up(NP * s_pad * g.Hp * g.Wp * 32, 256);
-    l.params_off = off; off += round_up(s_pad * g.ngb * g.GP * g.nfb * 64 * kParamDwords * 4, 256);
-    l.partial_off = off; off += round_up((size_t)g.chunks * kNumK * c.sh.S * c.sh.G * c.sh.F * 4, 256);
+    const size_t nsub = (size_t)g.nsub1 * g.nsub1;
+    l.params_off = off; off += round_up(nsub * s_pad * g.ngb * g.GP * g.nfb * 64 * kParamDwords * 4, 256);
+    l.partial_off = off; off += round_up(nsub * g.chunks * kNumK * c.sh.S * c.sh.G * c.sh.F * 4, 256);
     l.total = off;
     return l;
 }
 
-// rows per band of blur4_pack_kernel so that raw planes + three filtered bands stay below ~72 KiB (two workgroups per CU)
-void blur4_plan(int H, int W, int k, int Hp, int* band, size_t* lds) {
-    const size_t raw = (size_t)(H + k - 1) * (W + k - 1) * 8;
-    int b = Hp;
-    while (b > 8 && raw + (size_t)3 * (b + k - 1) * W * 8 > 72 * 1024) b = (b + 1) / 2;
-    *band = b;
-    *lds = raw + (size_t)3 * (b + k - 1) * W * 8;
+// output window of blur4_pack_kernel: up to 64 columns, and as many rows (a multiple of 8) as keep the raw window plus
+// the three filtered copies below ~74 KiB, so that two workgroups share a CU
+void blur4_plan(int k, int Hp, int Wp, int* wy, int* wx, size_t* lds) {
+    const int WX = Wp < 64 ? Wp : 64;
+    auto bytes = [&](int WY) { return ((size_t)(WY + k - 1) * (WX + k - 1) + (size_t)3 * (WY + k - 1) * WX) * 8; };
+    int WY = Hp;
+    while (WY > 8 && bytes(WY) > 74 * 1024) WY -= 8;
+    *wy = WY; *wx = WX; *lds = bytes(WY);
 }
 
 template <int GP, int AS>
@@ -540,12 +568,13 @@ void launch_dot(hipStream_t st, const DotArgs& a, int grid, size_t lds) {
 
 bool tiled_dot_configure(const Shape& sh, int R, int blur_k, TiledDotConfig* cfg) {
     const DotGeometry g = make_dot_geometry(sh, R);
-    if (g.tile_bytes > 160 * 1024) return false;                 // R <= 8 (8x8 regions: (8 + 2R + 1)^2 positions of 256 B)
+    if (g.tile_bytes > 160 * 1024) return false;
+    if ((size_t)64 * (sh.W | 1) * 4 > 160 * 1024) return false;   // pack_error_kernel transposes whole rows through LDS
     // immediates of the unrolled column walk must fit 16 bits
     if ((size_t)g.epitch * kDF * 8 + (kRW + 1) * kDF * 8 > 65535) return false;
     {
-        int band; size_t blur_lds;
-        blur4_plan(sh.H, sh.W, blur_k, g.Hp, &band, &blur_lds);
+        int wy, wx; size_t blur_lds;
+        blur4_plan(blur_k, g.Hp, g.Wp, &wy, &wx, &blur_lds);
         if (blur_lds > 150 * 1024) return false;
     }
     TiledDotConfig c{};
@@ -567,27 +596,35 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
     const int s_pad = g.nsb * g.sblock;
     {
         const size_t lds = (size_t)64 * (s.W | 1) * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pack_error_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
         hipLaunchKernelGGL(pack_error_kernel, dim3(c.NP * g.nfb * g.EY), dim3(256), lds, st, dy, s.N, s.F, s.H, s.W, c.R, g.EX,
                            g.EY, g.nfb, drop_col, drop_row, reinterpret_cast<float*>(ws + l.ep_off));
     }
     {
         // channels beyond S (padding of the last input-channel block) must read as zero
         if (s_pad != s.S) (void)hipMemsetAsync(ws + l.xk_off, 0, (size_t)c.NP * s_pad * g.Hp * g.Wp * 32, st);
-        int band; size_t blur_lds;
-        blur4_plan(s.H, s.W, c.blur_k, g.Hp, &band, &blur_lds);
+        int wy, wx; size_t blur_lds;
+        blur4_plan(c.blur_k, g.Hp, g.Wp, &wy, &wx, &blur_lds);
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blur4_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL(blur4_pack_kernel, dim3(c.NP * s.S), dim3(512), blur_lds, st, x, filters + kTaps1dOffset, s.N, s.S, s_pad,
-                           s.H, s.W, c.blur_k, g.Hp, g.Wp, band, reinterpret_cast<float*>(ws + l.xk_off));
+        Blur4Args b{};
+        b.in = x; b.taps = filters + kTaps1dOffset; b.xk = reinterpret_cast<float*>(ws + l.xk_off);
+        b.N = s.N; b.C = s.S; b.cstride = s_pad; b.H = s.H; b.W = s.W; b.k = c.blur_k; b.Hp = g.Hp; b.Wp = g.Wp;
+        b.WY = wy; b.WX = wx; b.nwy = (g.Hp + wy - 1) / wy; b.nwx = (g.Wp + wx - 1) / wx;
+        hipLaunchKernelGGL(blur4_pack_kernel, dim3(c.NP * b.nwy * b.nwx * s.S), dim3(512), blur_lds, st, b);
     }
     {
-        const long total = (long)s_pad * g.ngb * g.GP * g.nfb * 64;
+        const long total = (long)g.nsub1 * g.nsub1 * s_pad * g.ngb * g.GP * g.nfb * 64;
         const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL(dot_params_kernel, dim3(grid), dim3(256), 0, st, table_bare, s.S, s.G, s.F, c.R, g.epitch, g.GP,
-                           g.ngb, g.nfb, s_pad, reinterpret_cast<float*>(ws + l.params_off));
+        hipLaunchKernelGGL(dot_params_kernel, dim3(grid), dim3(256), 0, st, table_bare, s.S, s.G, s.F, c.R, g.Rt, g.nsub1,
+                           g.epitch, g.GP, g.ngb, g.nfb, s_pad, reinterpret_cast<float*>(ws + l.params_off));
     }
 }
 
@@ -602,12 +639,12 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
     a.params = reinterpret_cast<const float*>(ws + l.params_off);
     a.partial = reinterpret_cast<float*>(ws + l.partial_off);
     a.N = s.N; a.S = s.S; a.F = s.F; a.G = s.G; a.R = c.R;
-    a.NP = c.NP; a.nfb = g.nfb; a.nsb = g.nsb; a.ngb = g.ngb; a.nbuf = g.nbuf; a.chunks = g.chunks; a.items = g.items;
+    a.NP = c.NP; a.nfb = g.nfb; a.nsb = g.nsb; a.ngb = g.ngb; a.nbuf = g.nbuf; a.Rt = g.Rt; a.nsub1 = g.nsub1; a.chunks = g.chunks; a.items = g.items;
     a.rx = g.rx; a.ry = g.ry; a.EX = g.EX; a.EY = g.EY; a.Hp = g.Hp; a.Wp = g.Wp; a.epitch = g.epitch; a.erows = g.erows;
     a.s_pad = g.nsb * g.sblock;
     a.tile_bytes = (unsigned)g.tile_bytes;
     a.debug = getenv("DAU_DOT_DEBUG") ? atoi(getenv("DAU_DOT_DEBUG")) : 0;
-    const int grid = g.chunks * g.nfb * g.ngb * g.nsb;
+    const int grid = g.chunks * g.nsub1 * g.nsub1 * g.nfb * g.ngb * g.nsb;
     const size_t lds = (size_t)g.nbuf * g.tile_bytes;
     switch (g.GP) {
         case 1: launch_dot<1, 2>(st, a, grid, lds); break;
@@ -616,7 +653,7 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
     }
     const long n = (long)kNumK * s.S * s.G * s.F;
     const int rgrid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(dot_reduce_kernel, dim3(rgrid), dim3(256), 0, st, a.partial, n, g.chunks, r4);
+    hipLaunchKernelGGL(dot_reduce_kernel, dim3(rgrid), dim3(256), 0, st, a.partial, n, g.chunks * g.nsub1 * g.nsub1, r4);
 }
 
 }  // namespace dau

@@ -72,7 +72,9 @@ const Variant kVariants[] = {
     {7, 7, 72, 1, 3, 1},    // 56x56, R=4, three waves per output channel (tuning alternative, DAU_GATHER_SPLIT=3)
 };
 
-Geometry make_geometry(int H, int W, int R) {
+size_t ut_stride_bytes(int G) { return round_up((size_t)G * kFB * kUnitDwords * 4, 1024); }
+
+Geometry make_geometry(int H, int W, int R, int G) {
     Geometry g{};
     g.H = H; g.W = W; g.R = R; g.variant = -1;
     const char* split_env = getenv("DAU_GATHER_SPLIT");      // tuning knob: waves per output channel
@@ -92,6 +94,10 @@ Geometry make_geometry(int H, int W, int R) {
             cols = v.tx * 8 + 2 * R; rows = v.ty * 8 + 2 * R;
         }
         if (cols > v.pitch) continue;
+        {   // two planes + two unit slices must fit the 160 KiB of LDS
+            const size_t plane = round_up(((size_t)rows * v.pitch + (v.edge ? (size_t)(2 * R + 1) * rows : 0)) * 8, 1024);
+            if (2 * plane + 2 * ut_stride_bytes(G) > 160 * 1024) continue;
+        }
         const int npx = (W + pw - 1) / pw, npy = (H + ph - 1) / ph;
         // relative cost of one plane pass: MFMA tiles + a fixed part (barrier, unit fetch) + the DMA of the plane
         double cost = (double)npx * npy * (v.tx * v.ty + (v.edge ? 2 : 0) + 4 + 0.02 * rows * v.pitch / 8.0);
@@ -500,8 +506,6 @@ size_t blur_pack_lds_bytes(const Geometry& g, int k) {
     return ((wh + k - 1) * (ww + k - 1) + (wh + k - 1) * ww) * 8;
 }
 
-size_t ut_stride_bytes(int G) { return round_up((size_t)G * kFB * kUnitDwords * 4, 1024); }
-
 size_t lds_bytes(const TiledConfig& c, const Geometry& g) {
     const size_t main_b = 2 * g.plane_bytes + 2 * ut_stride_bytes(c.G);
     const size_t zpitch = g.pw + 2;
@@ -512,7 +516,7 @@ size_t lds_bytes(const TiledConfig& c, const Geometry& g) {
 }  // namespace
 
 bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, TiledConfig* cfg) {
-    const Geometry g = make_geometry(H, W, R);
+    const Geometry g = make_geometry(H, W, R, G);
     if (g.variant < 0) return false;
     TiledConfig c{};
     c.N = N; c.Cin = Cin; c.Cout = Cout; c.G = G; c.H = H; c.W = W; c.R = R; c.blur_k = blur_k;
@@ -527,14 +531,14 @@ bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R
 }
 
 size_t tiled_gather_workspace_bytes(const TiledConfig& c) {
-    const Geometry g = make_geometry(c.H, c.W, c.R);
+    const Geometry g = make_geometry(c.H, c.W, c.R, c.G);
     const size_t nfb = (c.Cout + kFB - 1) / kFB;
     return round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256) + round_up(nfb * c.Cin * ut_stride_bytes(c.G), 256);
 }
 
 void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in, const float* filters, bool mirrored,
                           const UnitRef* table, void* workspace) {
-    const Geometry g = make_geometry(c.H, c.W, c.R);
+    const Geometry g = make_geometry(c.H, c.W, c.R, c.G);
     char* staged = static_cast<char*>(workspace);
     char* packed = staged + round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256);
     const size_t blur_lds = blur_pack_lds_bytes(g, c.blur_k);
@@ -562,7 +566,7 @@ void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in,
 }
 
 void tiled_gather_run(hipStream_t st, const TiledConfig& c, float* out, void* workspace) {
-    const Geometry g = make_geometry(c.H, c.W, c.R);
+    const Geometry g = make_geometry(c.H, c.W, c.R, c.G);
     GatherArgs a{};
     a.staged = static_cast<const char*>(workspace);
     a.packed = a.staged + round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256);

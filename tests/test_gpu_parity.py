@@ -65,11 +65,12 @@ def test_tiled_kernels_are_selected_for_benchmark_shapes():
     for (H, W, k) in ((56, 56, 9), (32, 32, 9), (32, 32, 17), (16, 16, 9), (8, 8, 9), (27, 27, 9), (28, 28, 9), (24, 24, 9),
                       # patch decomposition: feature maps of ResNet / CIFAR stages, odd sizes, large images, kernels 17 and 33
                       (14, 14, 9), (7, 7, 9), (64, 64, 9), (112, 112, 9), (8, 65, 9), (90, 100, 9), (224, 224, 9), (56, 56, 17),
-                      (64, 64, 33), (128, 96, 17)):
+                      (64, 64, 33), (128, 96, 17), (512, 512, 33)):
         info = _capi.Plan(2, 4, 8, 2, H, W, max_kernel_size=k).info
         assert info["algo_forward"] == _capi.ALGO_TILED, (H, W, k, info)
     # gather-dot: any image size, any unit count, kernels 9 and 17
-    for (H, W, k, G) in ((56, 56, 9, 4), (27, 27, 9, 4), (65, 8, 9, 2), (32, 32, 17, 6), (56, 56, 17, 8), (100, 90, 9, 1)):
+    for (H, W, k, G) in ((56, 56, 9, 4), (27, 27, 9, 4), (65, 8, 9, 2), (32, 32, 17, 6), (56, 56, 17, 8), (100, 90, 9, 1),
+                         (64, 64, 33, 4), (64, 64, 65, 9), (512, 512, 33, 9)):
         info = _capi.Plan(2, 4, 8, G, H, W, max_kernel_size=k).info
         assert info["algo_backward"] == _capi.ALGO_TILED, (H, W, k, G, info)
 
@@ -175,6 +176,9 @@ def test_error_convention():
     dict(N=3, W=14, H=14, S=8, F=16, G=4, k=9, m=3),
     dict(N=5, W=7, H=7, S=8, F=16, G=2, k=9, m=3),
     dict(N=2, W=75, H=33, S=3, F=8, G=2, k=17, m=7),
+    # offset windows of the gather-dot for kernels 33 and 65 with offsets over the whole range
+    dict(N=2, W=40, H=40, S=5, F=33, G=3, k=33, m=16),
+    dict(N=1, W=48, H=40, S=3, F=8, G=2, k=65, m=32),
     # unit counts of the reference's dau_units (1x1 .. 4x2): one, odd, six and eight units per channel
     dict(N=2, W=16, H=16, S=5, F=40, G=1, k=9, m=3),
     dict(N=2, W=24, H=24, S=6, F=32, G=3, k=9, m=3),
