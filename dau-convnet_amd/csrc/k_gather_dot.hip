@@ -141,9 +141,11 @@ struct Blur4Args {
     int WY, WX, nwy, nwx;       // output window (rows x columns of the Hp x Wp plane) and windows per plane
 };
 
+// K: compile-time prefilter support (taps live in SGPRs, tap loops unrolled); K = 0: any support
+template <int K>
 __global__ void __launch_bounds__(512) blur4_pack_kernel(const Blur4Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int C = a.C, H = a.H, W = a.W, k = a.k;
+    const int C = a.C, H = a.H, W = a.W, k = K ? K : a.k;
     int t = blockIdx.x;
     const int c = t % C; t /= C;
     const int wx = t % a.nwx; t /= a.nwx;
@@ -155,9 +157,16 @@ __global__ void __launch_bounds__(512) blur4_pack_kernel(const Blur4Args a) {
     const int lw = ow + 2 * kr, lh = oh + 2 * kr;
     f2* A = reinterpret_cast<f2*>(lds);                      // raw [lh][lw], image (oy0 - kr + r, ox0 - kr + xl)
     f2* B = A + (size_t)lh * lw;                             // [3][lh][ow]
-    const float* gx = a.taps + kTapGX * kTapPitch; const float* gy = a.taps + kTapGY * kTapPitch;
-    const float* ax = a.taps + kTapAX * kTapPitch; const float* ay = a.taps + kTapAY * kTapPitch;
-    const float* cx = a.taps + kTapCX * kTapPitch; const float* by = a.taps + kTapBY * kTapPitch;
+    const float* tp[6] = {a.taps + kTapGX * kTapPitch, a.taps + kTapAX * kTapPitch, a.taps + kTapCX * kTapPitch,
+                          a.taps + kTapGY * kTapPitch, a.taps + kTapAY * kTapPitch, a.taps + kTapBY * kTapPitch};
+    float tr[6][K ? K : 1];
+    if (K) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int i = 0; i < K; ++i) tr[q][i] = tp[q][i];
+    }
+    auto tap = [&](int q, int i) { return K ? tr[q][i] : tp[q][i]; };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int n0 = 2 * np, n1 = 2 * np + 1;
     const float* p0 = a.in + ((long)n0 * C + c) * H * W;
@@ -179,13 +188,15 @@ __global__ void __launch_bounds__(512) blur4_pack_kernel(const Blur4Args a) {
         const bool rowin = yy >= 0 && yy < H;
         for (int x = lane; x < ow; x += 64) {
             f2 h1 = {0.0f, 0.0f}, h2 = {0.0f, 0.0f}, h3 = {0.0f, 0.0f};
-            if (rowin)
+            if (rowin) {
+#pragma unroll
                 for (int i = 0; i < k; ++i) {
                     const f2 v = A[r * lw + x + i];
-                    h1 = __builtin_elementwise_fma(v, f2{gx[i], gx[i]}, h1);
-                    h2 = __builtin_elementwise_fma(v, f2{ax[i], ax[i]}, h2);
-                    h3 = __builtin_elementwise_fma(v, f2{cx[i], cx[i]}, h3);
+                    h1 = __builtin_elementwise_fma(v, f2{tap(0, i), tap(0, i)}, h1);
+                    h2 = __builtin_elementwise_fma(v, f2{tap(1, i), tap(1, i)}, h2);
+                    h3 = __builtin_elementwise_fma(v, f2{tap(2, i), tap(2, i)}, h3);
                 }
+            }
             B[(0 * lh + r) * ow + x] = h1; B[(1 * lh + r) * ow + x] = h2; B[(2 * lh + r) * ow + x] = h3;
         }
     }
@@ -196,15 +207,17 @@ __global__ void __launch_bounds__(512) blur4_pack_kernel(const Blur4Args a) {
         for (int xc = lane; xc < ow; xc += 64) {
             const int xx = ox0 + xc;
             f2 dw = {0.0f, 0.0f}, d1 = {0.0f, 0.0f}, d2 = {0.0f, 0.0f}, ds = {0.0f, 0.0f};
-            if (yy < H && xx < W)
+            if (yy < H && xx < W) {
+#pragma unroll
                 for (int j = 0; j < k; ++j) {
                     const f2 b1 = B[(0 * lh + yr + j) * ow + xc], b2 = B[(1 * lh + yr + j) * ow + xc], b3 = B[(2 * lh + yr + j) * ow + xc];
-                    dw = __builtin_elementwise_fma(b1, f2{gy[j], gy[j]}, dw);
-                    d1 = __builtin_elementwise_fma(b2, f2{gy[j], gy[j]}, d1);
-                    d2 = __builtin_elementwise_fma(b1, f2{ay[j], ay[j]}, d2);
-                    ds = __builtin_elementwise_fma(b3, f2{gy[j], gy[j]}, ds);
-                    ds = __builtin_elementwise_fma(b1, f2{by[j], by[j]}, ds);
+                    dw = __builtin_elementwise_fma(b1, f2{tap(3, j), tap(3, j)}, dw);
+                    d1 = __builtin_elementwise_fma(b2, f2{tap(3, j), tap(3, j)}, d1);
+                    d2 = __builtin_elementwise_fma(b1, f2{tap(4, j), tap(4, j)}, d2);
+                    ds = __builtin_elementwise_fma(b3, f2{tap(3, j), tap(3, j)}, ds);
+                    ds = __builtin_elementwise_fma(b1, f2{tap(5, j), tap(5, j)}, ds);
                 }
+            }
             out[(size_t)yy * a.Wp + xx] = f8{dw.x, dw.y, d1.x, d1.y, d2.x, d2.y, ds.x, ds.y};
         }
     }
@@ -609,16 +622,13 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
         if (s_pad != s.S) (void)hipMemsetAsync(ws + l.xk_off, 0, (size_t)c.NP * s_pad * g.Hp * g.Wp * 32, st);
         int wy, wx; size_t blur_lds;
         blur4_plan(c.blur_k, g.Hp, g.Wp, &wy, &wx, &blur_lds);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blur4_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
+        auto kern = c.blur_k == 7 ? blur4_pack_kernel<7> : c.blur_k == 5 ? blur4_pack_kernel<5> : c.blur_k == 9 ? blur4_pack_kernel<9> : blur4_pack_kernel<0>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         Blur4Args b{};
         b.in = x; b.taps = filters + kTaps1dOffset; b.xk = reinterpret_cast<float*>(ws + l.xk_off);
         b.N = s.N; b.C = s.S; b.cstride = s_pad; b.H = s.H; b.W = s.W; b.k = c.blur_k; b.Hp = g.Hp; b.Wp = g.Wp;
         b.WY = wy; b.WX = wx; b.nwy = (g.Hp + wy - 1) / wy; b.nwx = (g.Wp + wx - 1) / wx;
-        hipLaunchKernelGGL(blur4_pack_kernel, dim3(c.NP * b.nwy * b.nwx * s.S), dim3(512), blur_lds, st, b);
+        hipLaunchKernelGGL(kern, dim3(c.NP * b.nwy * b.nwx * s.S), dim3(512), blur_lds, st, b);
     }
     {
         const long total = (long)g.nsub1 * g.nsub1 * s_pad * g.ngb * g.GP * g.nfb * 64;

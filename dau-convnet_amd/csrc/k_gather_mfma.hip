@@ -132,9 +132,11 @@ struct BlurPackArgs {
     size_t plane_floats;
 };
 
+// K: compile-time prefilter support (taps live in SGPRs, tap loops unrolled); K = 0: any support, taps re-read per use
+template <int K>
 __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int C = a.C, H = a.H, W = a.W, R = a.R, k = a.k;
+    const int C = a.C, H = a.H, W = a.W, R = a.R, k = K ? K : a.k;
     const int c = blockIdx.x % C;
     const int npp = blockIdx.x / C;                // (image pair, patch)
     const int npatch = a.npx * a.npy;
@@ -148,8 +150,15 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
     const int lw = bw + 2 * kr, lh = (ya1 - ya0) + 2 * kr;
     f2* A = reinterpret_cast<f2*>(lds);          // raw window, zero outside the image   [lh][lw]
     f2* B = A + (size_t)lh * lw;                  // after the horizontal pass            [lh][bw]
-    const float* gx = a.taps + (a.mirrored ? kTapGXR : kTapGX) * kTapPitch;
-    const float* gy = a.taps + (a.mirrored ? kTapGYR : kTapGY) * kTapPitch;
+    const float* gxp = a.taps + (a.mirrored ? kTapGXR : kTapGX) * kTapPitch;
+    const float* gyp = a.taps + (a.mirrored ? kTapGYR : kTapGY) * kTapPitch;
+    float gxr[K ? K : 1], gyr[K ? K : 1];
+    if (K) {
+#pragma unroll
+        for (int i = 0; i < K; ++i) { gxr[i] = gxp[i]; gyr[i] = gyp[i]; }
+    }
+    auto gx = [&](int i) { return K ? gxr[i] : gxp[i]; };
+    auto gy = [&](int i) { return K ? gyr[i] : gyp[i]; };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int n0 = 2 * np, n1 = 2 * np + 1;
     const float* p0 = a.in + ((long)n0 * C + c) * H * W;
@@ -171,8 +180,10 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
         const bool rowin = yy >= 0 && yy < H;
         for (int x = lane; x < bw; x += 64) {
             f2 acc = {0.0f, 0.0f};
-            if (rowin)
-                for (int i = 0; i < k; ++i) acc = __builtin_elementwise_fma(A[r * lw + x + i], f2{gx[i], gx[i]}, acc);
+            if (rowin) {
+#pragma unroll
+                for (int i = 0; i < k; ++i) acc = __builtin_elementwise_fma(A[r * lw + x + i], f2{gx(i), gx(i)}, acc);
+            }
             B[r * bw + x] = acc;
         }
     }
@@ -185,8 +196,10 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
         for (int col = lane; col < a.pitch; col += 64) {
             const int ix = wx0 + col;
             f2 acc = {0.0f, 0.0f};
-            if (rowin && ix >= xa0 && ix < xa1)
-                for (int j = 0; j < k; ++j) acc = __builtin_elementwise_fma(B[(iy - ya0 + j) * bw + (ix - xa0)], f2{gy[j], gy[j]}, acc);
+            if (rowin && ix >= xa0 && ix < xa1) {
+#pragma unroll
+                for (int j = 0; j < k; ++j) acc = __builtin_elementwise_fma(B[(iy - ya0 + j) * bw + (ix - xa0)], f2{gy(j), gy(j)}, acc);
+            }
             out[row * a.pitch + col] = acc;
             // columns pw .. pw+2R are stored a second time column-major: the edge-column tile of the gather reads a
             // vertical run of positions, which is bank-conflict free only in this orientation
@@ -542,18 +555,16 @@ void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in,
     char* staged = static_cast<char*>(workspace);
     char* packed = staged + round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256);
     const size_t blur_lds = blur_pack_lds_bytes(g, c.blur_k);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blur_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    // sigma = 0.5 (the reference's default) gives a 7-tap prefilter; other supports take the generic instantiation
+    auto kern = c.blur_k == 7 ? blur_pack_kernel<7> : c.blur_k == 5 ? blur_pack_kernel<5> : c.blur_k == 9 ? blur_pack_kernel<9> : blur_pack_kernel<0>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     BlurPackArgs b{};
     b.in = in; b.taps = filters + kTaps1dOffset; b.staged = reinterpret_cast<float*>(staged);
     b.mirrored = mirrored ? 1 : 0; b.N = c.N; b.C = c.Cin; b.H = c.H; b.W = c.W; b.R = c.R; b.k = c.blur_k;
     b.ph = g.ph; b.pw = g.pw; b.npx = g.npx; b.npy = g.npy;
     b.rows = g.rows; b.pitch = g.pitch; b.cols = g.cols; b.strip_cols = g.edge ? 2 * c.R + 1 : 0;
     b.plane_floats = g.plane_bytes / 4;
-    hipLaunchKernelGGL(blur_pack_kernel, dim3(c.NP * c.patches * c.Cin), dim3(512), blur_lds, st, b);
+    hipLaunchKernelGGL(kern, dim3(c.NP * c.patches * c.Cin), dim3(512), blur_lds, st, b);
     const int nfb = (c.Cout + kFB - 1) / kFB;
     const size_t uts = ut_stride_bytes(c.G);
     // packed slices are padded to whole KiB; zero the padding once per call together with the payload
