@@ -1,0 +1,74 @@
+"""GPU: seeded random configurations (shape, unit count, kernel size, flags, sigma) through the C ABI against the C
+oracle.  The reference's tests walk a fixed matrix (dau_conv_test.py:418-501); this sweep adds the combinations in
+between: ragged image sizes that exercise the patch / region / window decompositions of the tiled kernels, odd channel
+counts (partial channel blocks), every flag, ignored units, and prefilter supports other than the 7 taps of sigma 0.5.
+Tolerance: 1e-4 relative (util.assert_parity)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dau_oracle as orc
+from util import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _config(seed):
+    rs = np.random.RandomState(1000 + seed)
+    k = int(rs.choice([9, 9, 9, 17, 17, 33, 65]))
+    H = int(rs.randint(5, 80)); W = int(rs.randint(5, 80))
+    if seed % 7 == 0:
+        H, W = int(rs.choice([56, 64, 96, 112])), int(rs.choice([56, 64, 72, 120]))
+    G = int(rs.choice([1, 2, 2, 3, 4, 4, 5, 6, 8, 9]))
+    # keep the oracle's work bounded (~2e9 unit-pixel-taps)
+    budget = 6.0e6 / (H * W * G)
+    S = int(max(1, min(40, rs.randint(1, 41))))
+    F = int(max(1, min(70, rs.randint(1, 71))))
+    N = int(rs.randint(1, 6))
+    while N * S * F > budget and (S > 1 or F > 1 or N > 1):
+        if N > 1: N -= 1
+        elif S >= F: S = max(1, S // 2)
+        else: F = max(1, F // 2)
+    flags = dict(use_interpolation=bool(rs.rand() > 0.15), single_dim_kernel=bool(rs.rand() < 0.15),
+                 forbid_positive_dim1=bool(rs.rand() < 0.15))
+    unit_testing = bool(rs.rand() < 0.5)
+    ignore = int(rs.randint(0, G)) if rs.rand() < 0.25 else 0
+    sigma = float(rs.choice([0.5, 0.5, 0.5, 0.3, 0.8, 1.0, 1.4]))
+    return dict(N=N, S=S, F=F, G=G, H=H, W=W, k=k, flags=flags, unit_testing=unit_testing, ignore=ignore, sigma=sigma,
+                m=float(rs.uniform(0.5, k // 2)), seed=seed)
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_configuration(seed):
+    from dau_conv import _capi
+    c = _config(seed)
+    rs = np.random.RandomState(c["seed"])
+    N, S, F, G, H, W, k = (c[q] for q in ("N", "S", "F", "G", "H", "W", "k"))
+    x = rs.rand(N, S, H, W).astype(np.float32)
+    dy = rs.randn(N, F, H, W).astype(np.float32)
+    w = (rs.randn(1, S, G, F) * 0.1).astype(np.float32)
+    lim = k // 2 - 0.01
+    mu1 = np.clip(rs.uniform(-c["m"], c["m"], (1, S, G, F)), -lim, lim).astype(np.float32)
+    mu2 = np.clip(rs.uniform(-c["m"], c["m"], (1, S, G, F)), -lim, lim).astype(np.float32)
+    if c["flags"]["single_dim_kernel"]:
+        mu2[:] = 0.0
+    fl = 0
+    if c["flags"]["use_interpolation"]: fl |= _capi.FLAG_USE_INTERPOLATION
+    if c["flags"]["single_dim_kernel"]: fl |= _capi.FLAG_SINGLE_DIM_KERNEL
+    if c["flags"]["forbid_positive_dim1"]: fl |= _capi.FLAG_FORBID_POSITIVE_DIM1
+    if c["unit_testing"]: fl |= _capi.FLAG_UNIT_TESTING
+    lr = 10.0
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, number_units_ignore=c["ignore"], flags=fl, sigma_hint=c["sigma"],
+                      mu_learning_rate_factor=lr)
+    dev = lambda a: torch.from_numpy(a).cuda()
+    sig = torch.full((1, S, G, F), c["sigma"], device="cuda")
+    y = plan.forward(dev(x), dev(w), dev(mu1), dev(mu2), sig)
+    got = plan.backward(dev(x), dev(dy), dev(w), dev(mu1), dev(mu2), sig)
+    plan.check_status()
+    kw = dict(ignore=c["ignore"], **c["flags"])
+    want_y = orc.forward(x, w, mu1, mu2, c["sigma"], **kw)
+    want = orc.backward(x, dy, w, mu1, mu2, c["sigma"], unit_testing=c["unit_testing"], mu_learning_rate_factor=lr, **kw)
+    tag = "seed%d %s " % (seed, {q: c[q] for q in ("N", "S", "F", "G", "H", "W", "k", "sigma", "ignore")})
+    assert_parity(y.cpu().numpy(), want_y, tag + "y")
+    for t, key in zip(got, ("dx", "dw", "dmu1", "dmu2", "dsigma")):
+        assert_parity(t.cpu().numpy(), want[key], tag + key)
