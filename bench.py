@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
+    ap.add_argument("--shape", default=None, help="ad-hoc workload N,S,F,H,W,G,k[,m] (overrides --workload)")
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 direct, 2 tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -78,6 +79,10 @@ def main():
     from dau_conv import _capi
 
     wl = WORKLOADS[args.workload]
+    if args.shape:
+        v = args.shape.split(",")
+        wl = dict(N=int(v[0]), S=int(v[1]), F=int(v[2]), H=int(v[3]), W=int(v[4]), G=int(v[5]), k=int(v[6]),
+                  m=float(v[7]) if len(v) > 7 else 3.0, label="ad-hoc " + args.shape)
     N, S, F, H, W, G, k, m = (wl[q] for q in ("N", "S", "F", "H", "W", "G", "k", "m"))
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
@@ -147,7 +152,7 @@ def main():
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["kernels"]
         key = {"gather_dot": "dau::gather_dot_kernel", "gather_sum_fwd": "dau::gather_mfma_kernel",
                "gather_sum_dx": "dau::gather_mfma_kernel"}.get(dominant, "")
-        hits = [v["hbm_bytes"] for k, v in pmc.items() if k.startswith(key)] if key and args.workload == "ns" else []
+        hits = [v["hbm_bytes"] for k, v in pmc.items() if k.startswith(key)] if key and args.workload == "ns" and not args.shape else []
         traffic = round(hits[0] / 1e9, 3) if hits else None
     except Exception:
         traffic = None

@@ -13,6 +13,7 @@ struct TiledConfig {
     int R;            // offset bucket
     int blur_k;       // prefilter support
     int NP;           // image pairs = ceil(N/2)
+    int stack;        // (image pair, patch) planes gathered per workgroup
     int patches;      // patches per image: big or odd-sized images are gathered patch by patch
     int rows, pitch;  // staged plane of a patch: rows = ph + 2R + 1, pitch (in positions) >= pw + 2R + 1 with pitch % 32 == 8
     int tiles_x, tiles_y;   // 8x8 position tiles of a patch
@@ -34,6 +35,7 @@ struct TiledDotConfig {
     int R, blur_k;
     int NP;
     int variant;
+    int windows;      // offset-window passes: 1 for R <= 8, 4 for R = 16, 16 for R = 32
 };
 
 bool tiled_dot_configure(const Shape& sh, int R, int blur_k, TiledDotConfig* cfg);

@@ -591,7 +591,7 @@ bool tiled_dot_configure(const Shape& sh, int R, int blur_k, TiledDotConfig* cfg
         if (blur_lds > 150 * 1024) return false;
     }
     TiledDotConfig c{};
-    c.sh = sh; c.R = R; c.blur_k = blur_k; c.NP = (sh.N + 1) / 2; c.variant = g.GP;
+    c.sh = sh; c.R = R; c.blur_k = blur_k; c.NP = (sh.N + 1) / 2; c.variant = g.GP; c.windows = g.nsub1 * g.nsub1;
     *cfg = c;
     return true;
 }

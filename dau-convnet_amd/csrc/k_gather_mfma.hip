@@ -37,7 +37,7 @@ typedef __attribute__((address_space(1))) const void* glb_ptr_t;
 
 namespace {
 
-constexpr int kFB = 4;            // output channels per workgroup
+constexpr int kFB = 4;            // output channels per workgroup (default; small-map variants take 8 or 16)
 constexpr int kUnitDwords = 8;    // packed unit: {w00,off,w01,off,w10,offT,w11,offT} (offT: displacement in the transposed strip)
 
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -54,58 +54,84 @@ struct Geometry {
     int tx, ty;               // regular 8x8 tiles of a patch
     int edge;                 // 1: separate edge tiles for the extra row / column of Z; 0: regular tiles cover (H+1)x(W+1)
     int variant;              // row of kVariants, -1: no instantiated kernel fits
+    int sk;                   // (image pair, patch) planes stacked per workgroup
+    int fb;                   // output channels per workgroup
     int strip_pitch;          // EDGE: rows of the transposed strip (columns pw .. pw+2R of the plane, column-major)
     size_t strip_off;         // byte offset of the strip inside a staged plane
     size_t plane_bytes;       // padded to 1 KiB (one global_load_lds wave instruction)
 };
 
-struct Variant { int tx, ty, pitch, edge, split, tuning; };
+struct Variant { int tx, ty, pitch, edge, split, sk, plane_bytes, fb, tuning; };
 // instantiated kernels (add rows here and in the dispatch of tiled_gather_run)
 const Variant kVariants[] = {
-    {7, 7, 72, 1, 2, 0},    // 56x56 patches, R=4
-    {7, 7, 104, 1, 2, 0},   // 56x56 patches, R=8/16
-    {4, 4, 72, 1, 1, 0},    // 32x32 patches, R<=16
-    {2, 2, 40, 1, 1, 0},    // 16x16 patches, R<=8
-    {3, 3, 40, 1, 1, 0},    // 24x24 patches, R=4
-    {1, 1, 40, 1, 1, 0},    // 8x8 patches, R<=8
-    {4, 4, 40, 0, 1, 0},    // one 25..31 pixel image (27x27, 28x28), R=4
-    {7, 7, 72, 1, 3, 1},    // 56x56, R=4, three waves per output channel (tuning alternative, DAU_GATHER_SPLIT=3)
+    {7, 7, 72, 1, 2, 1, 0, 4, 0},       // 0: 56x56 patches, R=4
+    {7, 7, 104, 1, 2, 1, 0, 4, 0},      // 1: 56x56 patches, R=8/16
+    {4, 4, 72, 1, 1, 1, 0, 4, 0},       // 2: 32x32 patches, R<=16
+    {2, 2, 40, 1, 1, 1, 0, 4, 0},       // 3: 16x16 patches, R<=8
+    {3, 3, 40, 1, 1, 1, 0, 4, 0},       // 4: 24x24 patches, R=4
+    {1, 1, 40, 1, 1, 1, 0, 4, 0},       // 5: 8x8 patches, R<=8
+    {4, 4, 40, 0, 1, 1, 0, 4, 0},       // 6: one 25..31 pixel image (27x27, 28x28), R=4
+    {7, 7, 72, 1, 3, 1, 0, 4, 1},       // 7: 56x56, R=4, three waves per output channel (tuning alternative, DAU_GATHER_SPLIT=3)
+    // Small feature maps, R=4: several planes stacked per workgroup (plane size is part of the instantiation) and, for
+    // the smallest, more output channels per workgroup so that a staged plane is fetched from L2 less often per MFMA.
+    {4, 4, 72, 1, 2, 2, 26624, 4, 0},   // 8: 2 x 32x32 patches
+    {3, 3, 40, 1, 2, 4, 13312, 4, 0},   // 9: 4 x 24x24
+    {2, 2, 40, 1, 1, 3, 10240, 8, 0},   // 10: 3 x 16x16, 8 channels
+    {1, 1, 40, 1, 1, 3, 7168, 16, 0},   // 11: 3 x 8x8, 16 channels
+    {4, 4, 40, 0, 2, 3, 13312, 4, 0},   // 12: 3 x one 25..31 pixel image
+    // whole images of at most 23 / 15 / 7 pixels: the (H+1) x (W+1) domain of Z fits the regular tiles, no edge tiles
+    {3, 3, 40, 0, 1, 2, 10240, 8, 0},   // 13: 2 x one 17..23 pixel image, 8 channels
+    {2, 2, 40, 0, 1, 4, 8192, 8, 0},    // 14: 4 x one 9..15 pixel image (14x14), 8 channels
+    {1, 1, 40, 0, 1, 8, 5120, 16, 0},   // 15: 8 x one <=7 pixel image (7x7), 16 channels
 };
 
-size_t ut_stride_bytes(int G) { return round_up((size_t)G * kFB * kUnitDwords * 4, 1024); }
+size_t ut_stride_bytes(int G, int fb) { return round_up((size_t)G * fb * kUnitDwords * 4, 1024); }
 
-Geometry make_geometry(int H, int W, int R, int G) {
+// N, Cout only steer the choice between stacked and plain variants (enough workgroups to fill the chip)
+// only: >= 0 pins the row of kVariants (the plan's choice, so that every later call sees the same layout)
+Geometry make_geometry(int H, int W, int R, int G, int N, int Cout, int only = -1) {
     Geometry g{};
     g.H = H; g.W = W; g.R = R; g.variant = -1;
     const char* split_env = getenv("DAU_GATHER_SPLIT");      // tuning knob: waves per output channel
     const int want_split = split_env ? atoi(split_env) : 0;
+    // DAU_GATHER_VARIANT=<row> at plan creation pins the kernel (tests of the small-map variants on small batches)
+    if (only < 0 && getenv("DAU_GATHER_VARIANT")) only = atoi(getenv("DAU_GATHER_VARIANT"));
     double best = 0.0;
     for (int i = 0; i < (int)(sizeof(kVariants) / sizeof(kVariants[0])); ++i) {
         const Variant& v = kVariants[i];
-        if (v.tuning && v.split != want_split) continue;
+        if (only >= 0 && i != only) continue;
+        if (only < 0 && v.tuning && v.split != want_split) continue;
         int ph, pw, cols, rows;
         if (v.edge) {
             ph = v.ty * 8; pw = v.tx * 8;
             cols = pw + 1 + 2 * R; rows = ph + 1 + 2 * R;
         } else {
             // whole image in one patch, regular tiles cover the (H+1) x (W+1) domain of Z
-            if ((W + 1 + 7) / 8 != v.tx || (H + 1 + 7) / 8 != v.ty) continue;
+            if ((W + 1 + 7) / 8 > v.tx || (H + 1 + 7) / 8 > v.ty) continue;
             ph = H; pw = W;
             cols = v.tx * 8 + 2 * R; rows = v.ty * 8 + 2 * R;
         }
         if (cols > v.pitch) continue;
-        {   // two planes + two unit slices must fit the 160 KiB of LDS
-            const size_t plane = round_up(((size_t)rows * v.pitch + (v.edge ? (size_t)(2 * R + 1) * rows : 0)) * 8, 1024);
-            if (2 * plane + 2 * ut_stride_bytes(G) > 160 * 1024) continue;
-        }
+        const size_t plane = round_up(((size_t)rows * v.pitch + (v.edge ? (size_t)(2 * R + 1) * rows : 0)) * 8, 1024);
+        if (v.plane_bytes && plane != (size_t)v.plane_bytes) continue;
+        // two buffers of sk planes + two unit slices must fit the 160 KiB of LDS
+        if (2 * v.sk * plane + 2 * ut_stride_bytes(G, v.fb) > 160 * 1024) continue;
         const int npx = (W + pw - 1) / pw, npy = (H + ph - 1) / ph;
-        // relative cost of one plane pass: MFMA tiles + a fixed part (barrier, unit fetch) + the DMA of the plane
-        double cost = (double)npx * npy * (v.tx * v.ty + (v.edge ? 2 : 0) + 4 + 0.02 * rows * v.pitch / 8.0);
-        if (v.tuning) cost = 0.0;                            // explicitly requested
+        const long planes = (long)((N + 1) / 2) * npx * npy, groups = (planes + v.sk - 1) / v.sk;
+        // (DAU_GATHER_STACK=0 at plan creation: never stack, for A/B timing)
+        if (only < 0 && v.sk > 1 && getenv("DAU_GATHER_STACK") && atoi(getenv("DAU_GATHER_STACK")) == 0) continue;
+        const long blocks = groups * ((Cout + v.fb - 1) / v.fb);
+        // relative cost in tile units: MFMA tiles + the DMA of the planes + a fixed part per workgroup and channel
+        // (barrier, unit fetch, exposed LDS latency: ~12 tiles' worth, fitted to 28x28 stacked vs plain)
+        // (per four output channels: a workgroup with more channels fetches its planes and pays its barriers once for all)
+        double cost = (double)groups * (v.sk * (v.tx * v.ty + (v.edge ? 2 : 0) + 0.02 * rows * v.pitch / 8.0 * (4.0 / v.fb)) + 12.0 * (4.0 / v.fb));
+        // a grid that ends with a nearly empty round of workgroups wastes the chip: price the rounds, not the blocks
+        cost *= (double)((blocks + 255) / 256 * 256) / (double)blocks;
+        if (v.tuning && only < 0) cost = 0.0;                // explicitly requested
         if (g.variant >= 0 && cost >= best) continue;
         best = cost;
         g.variant = i; g.ph = ph; g.pw = pw; g.npx = npx; g.npy = npy; g.rows = rows; g.cols = cols; g.pitch = v.pitch;
-        g.tx = v.tx; g.ty = v.ty; g.edge = v.edge;
+        g.tx = v.tx; g.ty = v.ty; g.edge = v.edge; g.sk = v.sk; g.fb = v.fb;
     }
     if (g.variant < 0) return g;
     g.strip_pitch = g.rows;
@@ -212,7 +238,7 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
 // unit packing: UnitRef[Cin][G][Cout] -> packed[FBn][Cin] slices of [G][kFB][8 dwords], each slice padded to 1 KiB
 // ------------------------------------------------------------------------------------------------
 __global__ void pack_units_kernel(const UnitRef* __restrict__ table, int Cin, int G, int Cout, int pitch, int R,
-                                  int strip_pitch, int ut_stride_dwords, unsigned int* __restrict__ packed) {
+                                  int strip_pitch, int ut_stride_dwords, int kFB, unsigned int* __restrict__ packed) {
     const int nfb = (Cout + kFB - 1) / kFB;
     const long total = (long)nfb * Cin * G * kFB;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -249,16 +275,25 @@ struct GatherArgs {
     int debug;                 // timing experiments only (DAU_GATHER_DEBUG): 1 = no plane refills after the first two
 };
 
-// TX, TY : regular 8x8 tiles;  PITCH: staged pitch (positions);  EDGE: two extra edge tiles
+// TX, TY : regular 8x8 tiles of one plane;  PITCH: staged pitch (positions);  EDGE: two extra edge tiles per plane
 // SPLIT  : waves sharing one output channel (tiles are dealt out in contiguous ranges)
-template <int TX, int TY, int PITCH, bool EDGE, int SPLIT>
+// SK, PB : SK consecutive (image pair, patch) planes of PB bytes each are stacked in one LDS buffer and gathered by one
+//          workgroup (small feature maps: more tiles per wave against the per-channel fixed cost).  PB = 0 with SK = 1:
+//          plane size taken at run time.
+// FB     : output channels per workgroup (one wave, or SPLIT waves, each)
+template <int TX_, int TY_, int PITCH_, bool EDGE_, int SPLIT_, int SK_ = 1, int PB_ = 0, int FB_ = kFB>
 struct GatherTraits {
+    static constexpr int TX = TX_, TY = TY_, PITCH = PITCH_, SPLIT = SPLIT_, SK = SK_, PB = PB_, FB = FB_;
+    static constexpr bool EDGE = EDGE_;
     static constexpr int kRegular = TX * TY;
-    static constexpr int kTiles = kRegular + (EDGE ? 2 : 0);
+    static constexpr int kPlaneTiles = kRegular + (EDGE ? 2 : 0);
+    static constexpr int kTiles = SK * kPlaneTiles;
     static constexpr int kPerPart = (kTiles + SPLIT - 1) / SPLIT;
-    static constexpr int kWaves = kFB * SPLIT;
+    static constexpr int kWaves = FB * SPLIT;
     static constexpr int kThreads = kWaves * 64;
     static constexpr int kEpiF = 2;   // output channels assembled per epilogue round
+    static_assert(SK == 1 || PB > 0, "stacked planes need a compile-time plane size");
+    static_assert((SK - 1) * PB + ((TY * 8 - 1) * PITCH + TX * 8) * 8 < 65536, "LDS immediates are 16 bits");
 };
 
 template <int TX, int PITCH>
@@ -280,26 +315,29 @@ __device__ __forceinline__ void lds_wait() {
 
 constexpr int kBatch = 4;   // tiles per batch
 
-template <class T, int TX, int PITCH, int TILE>
+// TILE: index into the wave's flat tile list = stacked plane * kPlaneTiles + tile of that plane
+template <class T, int TILE>
 __device__ __forceinline__ void load_tile(f2& dst, unsigned addr, unsigned addr_e0, unsigned addr_e1) {
 #ifdef DAU_DIAG_NOLDS   // timing diagnosis only: no LDS tile reads (results are garbage)
     asm volatile("" : "=v"(dst) : "v"(addr), "v"(addr_e0), "v"(addr_e1));
     return;
 #endif
-    if constexpr (TILE < T::kRegular)
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(tile_imm<TX, PITCH>(TILE)) : "memory");
-    else if constexpr (TILE == T::kRegular)
-        asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr_e0) : "memory");
-    else if constexpr (TILE == T::kRegular + 1)
-        asm volatile("ds_read_b64 %0, %1" : "=v"(dst) : "v"(addr_e1) : "memory");
+    constexpr int plane = TILE / T::kPlaneTiles, t = TILE % T::kPlaneTiles;
+    constexpr unsigned poff = (unsigned)(plane * T::PB);
+    if constexpr (t < T::kRegular)
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(poff + tile_imm<T::TX, T::PITCH>(t)) : "memory");
+    else if constexpr (t == T::kRegular)
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr_e0), "n"(poff) : "memory");
+    else
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr_e1), "n"(poff) : "memory");
 }
 
-template <class T, int TX, int PITCH, int FIRST, int COUNT, int BATCH, int... J>
+template <class T, int FIRST, int COUNT, int BATCH, int... J>
 __device__ __forceinline__ void load_batch(f2 (&dst)[kBatch], unsigned addr, unsigned addr_e0, unsigned addr_e1,
                                            std::integer_sequence<int, J...>) {
     (([&] {
          if constexpr (BATCH * kBatch + J < COUNT)
-             load_tile<T, TX, PITCH, FIRST + BATCH * kBatch + J>(dst[J], addr, addr_e0, addr_e1);
+             load_tile<T, FIRST + BATCH * kBatch + J>(dst[J], addr, addr_e0, addr_e1);
      }()),
      ...);
 }
@@ -307,7 +345,7 @@ __device__ __forceinline__ void load_batch(f2 (&dst)[kBatch], unsigned addr, uns
 // A group of U consecutive units (same input channel, unit indices g .. g+U-1) runs as one straight-line block:
 // the batch list of all U units is flattened and the ds_read_b64 of flattened batch n+1 are issued before the MFMAs
 // of batch n (counted lgkmcnt), so the LDS latency is exposed once per group instead of once per unit.
-template <class T, int TX, int PITCH, int FIRST, int COUNT, int KP, int U, int FB>
+template <class T, int FIRST, int COUNT, int KP, int U, int FB>
 __device__ __forceinline__ void group_batches(f4 (&acc)[KP][2], f2 (&xv)[2][kBatch], const float (&wv)[U],
                                               const unsigned (&addr)[U], const unsigned (&addr_e0)[U],
                                               const unsigned (&addr_e1)[U]) {
@@ -318,8 +356,7 @@ __device__ __forceinline__ void group_batches(f4 (&acc)[KP][2], f2 (&xv)[2][kBat
     constexpr int left = COUNT - nb * kBatch;
     constexpr int next = more ? (left < kBatch ? left : kBatch) : 0;
     if constexpr (more)
-        load_batch<T, TX, PITCH, FIRST, COUNT, nb>(xv[(FB + 1) & 1], addr[nu], addr_e0[nu], addr_e1[nu],
-                                                   std::make_integer_sequence<int, kBatch>{});
+        load_batch<T, FIRST, COUNT, nb>(xv[(FB + 1) & 1], addr[nu], addr_e0[nu], addr_e1[nu], std::make_integer_sequence<int, kBatch>{});
     lds_wait<next>();
 #pragma unroll
     for (int j = 0; j < kBatch; ++j) {
@@ -330,14 +367,13 @@ __device__ __forceinline__ void group_batches(f4 (&acc)[KP][2], f2 (&xv)[2][kBat
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (more) group_batches<T, TX, PITCH, FIRST, COUNT, KP, U, FB + 1>(acc, xv, wv, addr, addr_e0, addr_e1);
+    if constexpr (more) group_batches<T, FIRST, COUNT, KP, U, FB + 1>(acc, xv, wv, addr, addr_e0, addr_e1);
 }
 
 // ut_addr: LDS address of this lane's slot in the first unit's table entry; entries are unit_pitch bytes apart.
-template <int TX, int TY, int PITCH, bool EDGE, int SPLIT, int PART, int KP, int U>
+template <class T, int PART, int KP, int U>
 __device__ __forceinline__ void unit_group(f4 (&acc)[KP][2], unsigned ut_addr, unsigned unit_pitch, unsigned pbase,
                                            unsigned lane_base, unsigned ebase0, unsigned ebase1) {
-    using T = GatherTraits<TX, TY, PITCH, EDGE, SPLIT>;
     constexpr int first = PART * T::kPerPart;
     constexpr int count = (first + KP <= T::kTiles) ? KP : (T::kTiles > first ? T::kTiles - first : 0);
     if constexpr (count > 0) {
@@ -357,20 +393,21 @@ __device__ __forceinline__ void unit_group(f4 (&acc)[KP][2], unsigned ut_addr, u
             addr[u] = lane_base + off; addr_e0[u] = ebase0 + off; addr_e1[u] = ebase1 + offt;
         }
         f2 xv[2][kBatch];
-        load_batch<T, TX, PITCH, first, count, 0>(xv[0], addr[0], addr_e0[0], addr_e1[0], std::make_integer_sequence<int, kBatch>{});
-        group_batches<T, TX, PITCH, first, count, KP, U, 0>(acc, xv, wv, addr, addr_e0, addr_e1);
+        load_batch<T, first, count, 0>(xv[0], addr[0], addr_e0[0], addr_e1[0], std::make_integer_sequence<int, kBatch>{});
+        group_batches<T, first, count, KP, U, 0>(acc, xv, wv, addr, addr_e0, addr_e1);
     }
 }
 
 // Whole per-wave program for one PART (the part only selects which tiles the wave owns, so that all
 // LDS immediates are compile-time constants; every wave runs the same number of barriers).
-template <int TX, int TY, int PITCH, bool EDGE, int SPLIT, int PART>
+template <class T, int PART>
 __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int lane, int wave, int fi) {
-    using T = GatherTraits<TX, TY, PITCH, EDGE, SPLIT>;
     constexpr int KP = T::kPerPart;
+    constexpr int TX = T::TX, TY = T::TY, PITCH = T::PITCH, SK = T::SK;
+    constexpr bool EDGE = T::EDGE;
 
-    // workgroup -> (image pair, channel block); blocks that share an image pair are made consecutive
-    // on one XCD (blocks b and b+8 share an XCD) so the staged planes are fetched into one L2.
+    // workgroup -> (group of SK consecutive (image pair, patch) planes, channel block); blocks that share planes are
+    // made consecutive on one XCD (blocks b and b+8 share an XCD) so the staged planes are fetched into one L2.
     const int nblk = gridDim.x;
     int logical;
     {
@@ -378,12 +415,11 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
         const int chunk = nblk / 8, rem = nblk % 8;
         logical = (xcd < rem ? xcd * (chunk + 1) : rem * (chunk + 1) + (xcd - rem) * chunk) + idx;
     }
-    const int npp = logical / a.nfb, fb = logical % a.nfb;      // (image pair, patch), channel block
+    const int npp0 = (logical / a.nfb) * SK, fb = logical % a.nfb;
     const int npatch = a.npx * a.npy;
-    const int np = npp / npatch, patch = npp % npatch;
-    const int y0 = (patch / a.npx) * (TY * 8), x0 = (patch % a.npx) * (TX * 8);   // patch origin (0 for the non-EDGE variant)
+    const int npp_total = ((a.N + 1) / 2) * npatch;
 
-    // H, W: the domain this workgroup computes (a patch; the whole image for the non-EDGE variant)
+    // H, W: the domain one plane covers (a patch; the whole image for the non-EDGE variant)
     const int R = a.R, H = EDGE ? TY * 8 : a.H, W = EDGE ? TX * 8 : a.W;
     const int ly = lane >> 3, lx = lane & 7;
     const unsigned lane_base = (unsigned)(((ly + R) * PITCH + (lx + R)) * 8);
@@ -400,17 +436,22 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
     const unsigned ebase0 = (unsigned)(((ey[0] + R) * PITCH + ex[0] + R) * 8);
     const unsigned ebase1 = (unsigned)(a.strip_off + (ey[1] + R) * 8);
 
-    const unsigned plane_bytes = a.plane_bytes, ut_stride = a.ut_stride;
-    const char* src_planes = a.staged + (size_t)npp * a.Cin * plane_bytes;
+    const unsigned plane_bytes = T::PB ? (unsigned)T::PB : a.plane_bytes, ut_stride = a.ut_stride;
+    const unsigned buf_bytes = SK * plane_bytes;
     const char* src_units = a.packed + (size_t)fb * a.Cin * ut_stride;
-    const unsigned ut_base = 2 * plane_bytes;
+    const unsigned ut_base = 2 * buf_bytes;
 
     auto issue = [&](int c, int buf) {
-        const char* ps = src_planes + (size_t)c * plane_bytes;
         const unsigned pieces = plane_bytes >> 10;
-        for (unsigned piece = wave; piece < pieces; piece += T::kWaves)
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(ps + (size_t)piece * 1024 + lane * 16),
-                                             (lds_ptr_t)(smem + buf * plane_bytes + piece * 1024), 16, 0, 0);
+#pragma unroll
+        for (int k = 0; k < SK; ++k) {
+            // the last group may be short: its missing planes re-read the last valid one (their output is not stored)
+            const int npp = npp0 + k < npp_total ? npp0 + k : npp_total - 1;
+            const char* ps = a.staged + ((size_t)npp * a.Cin + c) * plane_bytes;
+            for (unsigned piece = wave; piece < pieces; piece += T::kWaves)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(ps + (size_t)piece * 1024 + lane * 16),
+                                                 (lds_ptr_t)(smem + buf * buf_bytes + k * plane_bytes + piece * 1024), 16, 0, 0);
+        }
         const char* us = src_units + (size_t)c * ut_stride;
         const unsigned upieces = ut_stride >> 10;
         for (unsigned piece = wave; piece < upieces; piece += T::kWaves)
@@ -430,70 +471,80 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
         __syncthreads();   // plane c is in LDS for everyone; everyone is done reading plane c-1
 #endif
         if (c + 1 < a.Cin && !((a.debug & 1) && c >= 1)) issue(c + 1, buf ^ 1);
-        const unsigned pbase = buf * plane_bytes;
+        const unsigned pbase = buf * buf_bytes;
         const unsigned ut_addr = ut_base + buf * ut_stride + (fi * kUnitDwords + (lane & 3) * 2) * 4;
-        constexpr unsigned unit_pitch = kFB * kUnitDwords * 4;
+        constexpr unsigned unit_pitch = T::FB * kUnitDwords * 4;
         int g = 0;
         for (; g + 4 <= a.G; g += 4)
-            unit_group<TX, TY, PITCH, EDGE, SPLIT, PART, KP, 4>(acc, ut_addr + g * unit_pitch, unit_pitch, pbase, lane_base, ebase0, ebase1);
-        for (; g < a.G; ++g)
-            unit_group<TX, TY, PITCH, EDGE, SPLIT, PART, KP, 1>(acc, ut_addr + g * unit_pitch, unit_pitch, pbase, lane_base, ebase0, ebase1);
+            unit_group<T, PART, KP, 4>(acc, ut_addr + g * unit_pitch, unit_pitch, pbase, lane_base, ebase0, ebase1);
+        if (g + 2 <= a.G) {
+            unit_group<T, PART, KP, 2>(acc, ut_addr + g * unit_pitch, unit_pitch, pbase, lane_base, ebase0, ebase1);
+            g += 2;
+        }
+        if (g < a.G)
+            unit_group<T, PART, KP, 1>(acc, ut_addr + g * unit_pitch, unit_pitch, pbase, lane_base, ebase0, ebase1);
     }
 
     // ---- epilogue: out[p] = Z0[p] + Z1[p+(0,1)] + Z2[p+(1,0)] + Z3[p+(1,1)] through LDS ---------------
+    // per round: one image of the pair, kEpiF output channels, all SK planes
     const unsigned zpitch = a.zpitch;
     const unsigned zplane = (unsigned)(H + 1) * zpitch;       // floats per tap plane
+    const unsigned zchan = 4 * zplane;                        // floats per (plane, output channel)
     float* zs = reinterpret_cast<float*>(smem);
     const int HW = H * W;
     const long plane_out = (long)a.H * a.W;
 #pragma unroll
     for (int img = 0; img < 2; ++img) {   // unrolled: acc[i][img] must be a static register index
 #pragma unroll 1
-        for (int fh = 0; fh < kFB / T::kEpiF; ++fh) {
+        for (int fh = 0; fh < T::FB / T::kEpiF; ++fh) {
             __syncthreads();
             if (fi / T::kEpiF == fh) {
-                float* zf = zs + (size_t)(fi % T::kEpiF) * 4 * zplane;
 #pragma unroll
                 for (int i = 0; i < KP; ++i) {
                     constexpr int first = PART * KP;
-                    const int tile = first + i;
+                    const int flat = first + i;
+                    const int k = flat / T::kPlaneTiles, tile = flat % T::kPlaneTiles;
                     int y, x; bool ok;
-                    if (tile < T::kRegular) { y = (tile / TX) * 8 + ly; x = (tile % TX) * 8 + lx; ok = (y <= H) && (x <= W); }
+                    if (flat >= T::kTiles) { y = 0; x = 0; ok = false; }
+                    else if (tile < T::kRegular) { y = (tile / TX) * 8 + ly; x = (tile % TX) * 8 + lx; ok = (y <= H) && (x <= W); }
                     else if (tile == T::kRegular) { y = ey[0]; x = ex[0]; ok = evalid[0]; }
-                    else if (tile == T::kRegular + 1) { y = ey[1]; x = ex[1]; ok = evalid[1]; }
-                    else { y = 0; x = 0; ok = false; }
+                    else { y = ey[1]; x = ex[1]; ok = evalid[1]; }
                     if (ok) {
                         const f4 v = acc[i][img];
-                        float* q = zf + (unsigned)y * zpitch + x;
+                        float* q = zs + (size_t)(k * T::kEpiF + fi % T::kEpiF) * zchan + (unsigned)y * zpitch + x;
                         q[0] = v[0]; q[zplane] = v[1]; q[2 * zplane] = v[2]; q[3 * zplane] = v[3];
                     }
                 }
             }
             __syncthreads();
-            const int n = 2 * np + img;
-            for (int o = threadIdx.x; o < T::kEpiF * HW; o += T::kThreads) {
-                const int fl = o / HW;
+            for (int o = threadIdx.x; o < SK * T::kEpiF * HW; o += T::kThreads) {
+                const int kf = o / HW;                     // (plane, channel of the round)
+                const int k = kf / T::kEpiF, fl = kf % T::kEpiF;
                 const int p = o % HW, y = p / W, x = p % W;
-                const int f = fb * kFB + fh * T::kEpiF + fl;
-                const float* zf = zs + (size_t)fl * 4 * zplane + (unsigned)y * zpitch + x;
+                const int f = fb * T::FB + fh * T::kEpiF + fl;
+                const int npp = npp0 + k;
+                const int n = 2 * (npp / npatch) + img, patch = npp % npatch;
+                const int gy = (patch / a.npx) * H + y, gx = (patch % a.npx) * W + x;    // non-EDGE: one patch, origin 0
+                const float* zf = zs + (size_t)kf * zchan + (unsigned)y * zpitch + x;
                 const float v = zf[0] + zf[zplane + 1] + zf[2 * zplane + zpitch] + zf[3 * zplane + zpitch + 1];
-                if (n < a.N && f < a.Cout && y0 + y < a.H && x0 + x < a.W)
-                    a.out[((long)n * a.Cout + f) * plane_out + (long)(y0 + y) * a.W + (x0 + x)] = v;
+                if (npp < npp_total && n < a.N && f < a.Cout && gy < a.H && gx < a.W)
+                    a.out[((long)n * a.Cout + f) * plane_out + (long)gy * a.W + gx] = v;
             }
         }
     }
 }
 
-template <int TX, int TY, int PITCH, bool EDGE, int SPLIT>
-__global__ void __launch_bounds__(kFB * SPLIT * 64) gather_mfma_kernel(const GatherArgs a) {
+template <class T>
+__global__ void __launch_bounds__(T::kThreads) gather_mfma_kernel(const GatherArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SPLIT = T::SPLIT;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int part = wave % SPLIT, fi = wave / SPLIT;
-    if (SPLIT == 1 || part == 0) gather_body<TX, TY, PITCH, EDGE, SPLIT, 0>(a, smem, lane, wave, fi);
-    else if (SPLIT == 2 || part == 1) { if constexpr (SPLIT > 1) gather_body<TX, TY, PITCH, EDGE, SPLIT, 1>(a, smem, lane, wave, fi); }
-    else if (SPLIT == 3 || part == 2) { if constexpr (SPLIT > 2) gather_body<TX, TY, PITCH, EDGE, SPLIT, 2>(a, smem, lane, wave, fi); }
-    else { if constexpr (SPLIT > 3) gather_body<TX, TY, PITCH, EDGE, SPLIT, 3>(a, smem, lane, wave, fi); }
+    if (SPLIT == 1 || part == 0) gather_body<T, 0>(a, smem, lane, wave, fi);
+    else if (SPLIT == 2 || part == 1) { if constexpr (SPLIT > 1) gather_body<T, 1>(a, smem, lane, wave, fi); }
+    else if (SPLIT == 3 || part == 2) { if constexpr (SPLIT > 2) gather_body<T, 2>(a, smem, lane, wave, fi); }
+    else { if constexpr (SPLIT > 3) gather_body<T, 3>(a, smem, lane, wave, fi); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -501,10 +552,9 @@ __global__ void __launch_bounds__(kFB * SPLIT * 64) gather_mfma_kernel(const Gat
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-template <int TX, int TY, int PITCH, bool EDGE, int SPLIT>
+template <class T>
 void launch_variant(hipStream_t st, const GatherArgs& a, int grid, size_t lds) {
-    using T = GatherTraits<TX, TY, PITCH, EDGE, SPLIT>;
-    auto kern = gather_mfma_kernel<TX, TY, PITCH, EDGE, SPLIT>;
+    auto kern = gather_mfma_kernel<T>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -520,22 +570,22 @@ size_t blur_pack_lds_bytes(const Geometry& g, int k) {
 }
 
 size_t lds_bytes(const TiledConfig& c, const Geometry& g) {
-    const size_t main_b = 2 * g.plane_bytes + 2 * ut_stride_bytes(c.G);
+    const size_t main_b = 2 * g.sk * g.plane_bytes + 2 * ut_stride_bytes(c.G, g.fb);
     const size_t zpitch = g.pw + 2;
-    const size_t epi_b = (size_t)2 /*kEpiF*/ * 4 * (g.ph + 1) * zpitch * 4;
+    const size_t epi_b = (size_t)g.sk * 2 /*kEpiF*/ * 4 * (g.ph + 1) * zpitch * 4;
     return main_b > epi_b ? main_b : epi_b;
 }
 
 }  // namespace
 
 bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, TiledConfig* cfg) {
-    const Geometry g = make_geometry(H, W, R, G);
+    const Geometry g = make_geometry(H, W, R, G, N, Cout);
     if (g.variant < 0) return false;
     TiledConfig c{};
     c.N = N; c.Cin = Cin; c.Cout = Cout; c.G = G; c.H = H; c.W = W; c.R = R; c.blur_k = blur_k;
     c.NP = (N + 1) / 2;
-    c.rows = g.rows; c.pitch = g.pitch; c.tiles_x = g.tx; c.tiles_y = g.ty; c.fblock = kFB; c.variant = g.variant;
-    c.patches = g.npx * g.npy;
+    c.rows = g.rows; c.pitch = g.pitch; c.tiles_x = g.tx; c.tiles_y = g.ty; c.fblock = g.fb; c.variant = g.variant;
+    c.patches = g.npx * g.npy; c.stack = g.sk;
     if (lds_bytes(c, g) > 160 * 1024) return false;
     // blur_pack keeps both raw planes (+ blur halo) and the horizontally filtered rows in LDS
     if (blur_pack_lds_bytes(g, blur_k) > 150 * 1024) return false;
@@ -544,14 +594,14 @@ bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R
 }
 
 size_t tiled_gather_workspace_bytes(const TiledConfig& c) {
-    const Geometry g = make_geometry(c.H, c.W, c.R, c.G);
-    const size_t nfb = (c.Cout + kFB - 1) / kFB;
-    return round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256) + round_up(nfb * c.Cin * ut_stride_bytes(c.G), 256);
+    const Geometry g = make_geometry(c.H, c.W, c.R, c.G, c.N, c.Cout, c.variant);
+    const size_t nfb = (c.Cout + g.fb - 1) / g.fb;
+    return round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256) + round_up(nfb * c.Cin * ut_stride_bytes(c.G, g.fb), 256);
 }
 
 void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in, const float* filters, bool mirrored,
                           const UnitRef* table, void* workspace) {
-    const Geometry g = make_geometry(c.H, c.W, c.R, c.G);
+    const Geometry g = make_geometry(c.H, c.W, c.R, c.G, c.N, c.Cout, c.variant);
     char* staged = static_cast<char*>(workspace);
     char* packed = staged + round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256);
     const size_t blur_lds = blur_pack_lds_bytes(g, c.blur_k);
@@ -565,42 +615,50 @@ void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in,
     b.rows = g.rows; b.pitch = g.pitch; b.cols = g.cols; b.strip_cols = g.edge ? 2 * c.R + 1 : 0;
     b.plane_floats = g.plane_bytes / 4;
     hipLaunchKernelGGL(kern, dim3(c.NP * c.patches * c.Cin), dim3(512), blur_lds, st, b);
-    const int nfb = (c.Cout + kFB - 1) / kFB;
-    const size_t uts = ut_stride_bytes(c.G);
+    const int nfb = (c.Cout + g.fb - 1) / g.fb;
+    const size_t uts = ut_stride_bytes(c.G, g.fb);
     // packed slices are padded to whole KiB; zero the padding once per call together with the payload
     (void)hipMemsetAsync(packed, 0, (size_t)nfb * c.Cin * uts, st);
-    const long total = (long)nfb * c.Cin * c.G * kFB;
+    const long total = (long)nfb * c.Cin * c.G * g.fb;
     const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
     hipLaunchKernelGGL(pack_units_kernel, dim3(grid), dim3(256), 0, st, table, c.Cin, c.G, c.Cout, g.pitch, c.R, g.strip_pitch,
-                       (int)(uts / 4),
+                       (int)(uts / 4), g.fb,
                        reinterpret_cast<unsigned int*>(packed));
 }
 
 void tiled_gather_run(hipStream_t st, const TiledConfig& c, float* out, void* workspace) {
-    const Geometry g = make_geometry(c.H, c.W, c.R, c.G);
+    const Geometry g = make_geometry(c.H, c.W, c.R, c.G, c.N, c.Cout, c.variant);
     GatherArgs a{};
     a.staged = static_cast<const char*>(workspace);
     a.packed = a.staged + round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256);
     a.out = out;
     a.npx = g.npx; a.npy = g.npy;
     a.N = c.N; a.Cin = c.Cin; a.Cout = c.Cout; a.G = c.G; a.H = c.H; a.W = c.W; a.R = c.R;
-    a.nfb = (c.Cout + kFB - 1) / kFB;
+    a.nfb = (c.Cout + g.fb - 1) / g.fb;
     a.plane_bytes = (unsigned)g.plane_bytes;
     a.strip_off = (unsigned)g.strip_off;
-    a.ut_stride = (unsigned)ut_stride_bytes(c.G);
+    a.ut_stride = (unsigned)ut_stride_bytes(c.G, g.fb);
     a.zpitch = (unsigned)(g.pw + 2);
     a.debug = getenv("DAU_GATHER_DEBUG") ? atoi(getenv("DAU_GATHER_DEBUG")) : 0;
-    const int grid = c.NP * c.patches * a.nfb;
+    const int grid = ((c.NP * c.patches + g.sk - 1) / g.sk) * a.nfb;
     const size_t lds = lds_bytes(c, g);
     switch (c.variant) {
-        case 0: launch_variant<7, 7, 72, true, 2>(st, a, grid, lds); break;
-        case 1: launch_variant<7, 7, 104, true, 2>(st, a, grid, lds); break;
-        case 2: launch_variant<4, 4, 72, true, 1>(st, a, grid, lds); break;
-        case 3: launch_variant<2, 2, 40, true, 1>(st, a, grid, lds); break;
-        case 4: launch_variant<3, 3, 40, true, 1>(st, a, grid, lds); break;
-        case 5: launch_variant<1, 1, 40, true, 1>(st, a, grid, lds); break;
-        case 6: launch_variant<4, 4, 40, false, 1>(st, a, grid, lds); break;
-        case 7: launch_variant<7, 7, 72, true, 3>(st, a, grid, lds); break;
+        case 0: launch_variant<GatherTraits<7, 7, 72, true, 2>>(st, a, grid, lds); break;
+        case 1: launch_variant<GatherTraits<7, 7, 104, true, 2>>(st, a, grid, lds); break;
+        case 2: launch_variant<GatherTraits<4, 4, 72, true, 1>>(st, a, grid, lds); break;
+        case 3: launch_variant<GatherTraits<2, 2, 40, true, 1>>(st, a, grid, lds); break;
+        case 4: launch_variant<GatherTraits<3, 3, 40, true, 1>>(st, a, grid, lds); break;
+        case 5: launch_variant<GatherTraits<1, 1, 40, true, 1>>(st, a, grid, lds); break;
+        case 6: launch_variant<GatherTraits<4, 4, 40, false, 1>>(st, a, grid, lds); break;
+        case 7: launch_variant<GatherTraits<7, 7, 72, true, 3>>(st, a, grid, lds); break;
+        case 8: launch_variant<GatherTraits<4, 4, 72, true, 2, 2, 26624>>(st, a, grid, lds); break;
+        case 9: launch_variant<GatherTraits<3, 3, 40, true, 2, 4, 13312>>(st, a, grid, lds); break;
+        case 10: launch_variant<GatherTraits<2, 2, 40, true, 1, 3, 10240, 8>>(st, a, grid, lds); break;
+        case 11: launch_variant<GatherTraits<1, 1, 40, true, 1, 3, 7168, 16>>(st, a, grid, lds); break;
+        case 12: launch_variant<GatherTraits<4, 4, 40, false, 2, 3, 13312>>(st, a, grid, lds); break;
+        case 13: launch_variant<GatherTraits<3, 3, 40, false, 1, 2, 10240, 8>>(st, a, grid, lds); break;
+        case 14: launch_variant<GatherTraits<2, 2, 40, false, 1, 4, 8192, 8>>(st, a, grid, lds); break;
+        case 15: launch_variant<GatherTraits<1, 1, 40, false, 1, 8, 5120, 16>>(st, a, grid, lds); break;
         default: break;
     }
 }

@@ -54,7 +54,8 @@ class _Desc(ctypes.Structure):
 
 class _Info(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
-                ("offset_bucket", "blur_support", "algo_forward", "algo_backward", "drop_last_col", "drop_last_row")]
+                ("offset_bucket", "blur_support", "algo_forward", "algo_backward", "drop_last_col", "drop_last_row",
+                 "gather_patch", "gather_stack", "dot_windows")]
 
 
 def _load():

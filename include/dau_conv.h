@@ -122,6 +122,9 @@ typedef struct dau_conv_plan_info {
     int32_t algo_backward;     /* DAU_ALGO_* actually used for the parameter gradients            */
     int32_t drop_last_col;     /* unit_testing edge rule outcome for this W                       */
     int32_t drop_last_row;     /* ... and H                                                       */
+    int32_t gather_patch;      /* tiled gather-sum: pixels per patch side (0: direct kernel)      */
+    int32_t gather_stack;      /* ... and (image pair, patch) planes gathered per workgroup       */
+    int32_t dot_windows;       /* tiled gather-dot: offset-window passes (1 for kernels <= 17)    */
 } dau_conv_plan_info;
 
 DAU_API int dau_conv_abi_version(void);

@@ -212,3 +212,44 @@ def test_seeded_shapes_against_c_oracle(shape, algo):
     assert_parity(y.cpu().numpy(), want_y, "y")
     for t, key in zip(got, ("dx", "dw", "dmu1", "dmu2", "dsigma")):
         assert_parity(t.cpu().numpy(), want[key], key)
+
+
+@pytest.mark.parametrize("shape", [
+    # small feature maps with several (image pair, patch) planes stacked per workgroup; N chosen so that the last
+    # group is short (planes % stack != 0) and N is odd (zero image in the last pair)
+    dict(N=5, W=32, H=32, S=5, F=12, G=4, k=9, m=3, variant=8, stack=2, patch=32),
+    dict(N=7, W=24, H=24, S=4, F=8, G=2, k=9, m=3, variant=9, stack=4, patch=24),
+    dict(N=9, W=16, H=16, S=6, F=10, G=3, k=9, m=3, variant=10, stack=3, patch=16),    # 8 channels per workgroup
+    dict(N=21, W=8, H=8, S=8, F=20, G=4, k=9, m=3, variant=11, stack=3, patch=8),      # 16 channels per workgroup
+    dict(N=7, W=28, H=28, S=5, F=8, G=4, k=9, m=3, variant=12, stack=3, patch=32),     # whole 28x28 images
+    dict(N=3, W=27, H=27, S=3, F=8, G=6, k=9, m=3, variant=12, stack=3, patch=32),
+    dict(N=3, W=40, H=20, S=3, F=8, G=4, k=9, m=3, variant=9, stack=4, patch=24),      # two patch columns, stacked across patches and pairs
+    dict(N=5, W=21, H=19, S=4, F=12, G=4, k=9, m=3, variant=13, stack=2, patch=24),    # whole images, no edge tiles
+    dict(N=9, W=14, H=14, S=6, F=10, G=3, k=9, m=3, variant=14, stack=4, patch=16),    # 14x14 maps
+    dict(N=11, W=9, H=15, S=3, F=9, G=2, k=9, m=3, variant=14, stack=4, patch=16),
+    dict(N=21, W=7, H=7, S=8, F=20, G=4, k=9, m=3, variant=15, stack=8, patch=8),      # 7x7 maps
+    dict(N=3, W=5, H=6, S=8, F=33, G=5, k=9, m=3, variant=15, stack=8, patch=8),
+    dict(N=4, W=100, H=60, S=3, F=8, G=4, k=9, m=3, variant=8, stack=2, patch=32),     # a large image cut into stacked patches
+])
+def test_stacked_gather_variants(shape, monkeypatch):
+    from dau_conv import _capi
+    monkeypatch.setenv("DAU_GATHER_VARIANT", str(shape["variant"]))   # read at plan creation only
+    rs = np.random.RandomState(11)
+    N, S, F, G, H, W, k, m = (shape[q] for q in ("N", "S", "F", "G", "H", "W", "k", "m"))
+    x = rs.rand(N, S, H, W).astype(np.float32)
+    w = (rs.randn(1, S, G, F) * 0.1).astype(np.float32)
+    lim = k // 2 - 0.01
+    mu1 = np.clip(rs.uniform(-m, m, (1, S, G, F)), -lim, lim).astype(np.float32)
+    mu2 = np.clip(rs.uniform(-m, m, (1, S, G, F)), -lim, lim).astype(np.float32)
+    dy = rs.randn(N, F, H, W).astype(np.float32)
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, sigma_hint=0.5)
+    assert plan.info["algo_forward"] == _capi.ALGO_TILED
+    assert (plan.info["gather_stack"], plan.info["gather_patch"]) == (shape["stack"], shape["patch"]), plan.info
+    sigma = torch.full((1, S, G, F), 0.5, device="cuda")
+    y = plan.forward(_dev(x), _dev(w), _dev(mu1), _dev(mu2), sigma)
+    got = plan.backward(_dev(x), _dev(dy), _dev(w), _dev(mu1), _dev(mu2), sigma)
+    plan.check_status()
+    assert_parity(y.cpu().numpy(), orc.forward(x, w, mu1, mu2, 0.5), "y")
+    want = orc.backward(x, dy, w, mu1, mu2, 0.5)
+    for t, key in zip(got, ("dx", "dw", "dmu1", "dmu2", "dsigma")):
+        assert_parity(t.cpu().numpy(), want[key], key)
