@@ -290,10 +290,11 @@ __device__ __forceinline__ f2 pk_fma_s(f2 a, f2 s, f2 c) { return __builtin_elem
 #define lds_read_imm(dst, addr, imm) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
 // Xk ring: the destination is a read-write operand so that the register stays put across loop back-edges.
 #define x_load(dst, voff, sbase, imm) asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "+v"(dst) : "v"(voff), "s"(sbase), "n"(imm) : "memory")
-// ring of 8 loads: the two oldest are complete when at most 6 are outstanding
-__device__ __forceinline__ void x_wait6() {
+// ring of kXSlots loads: the oldest is complete when at most kXSlots - 1 (+ tile loads in between) are outstanding
+template <int N>
+__device__ __forceinline__ void x_wait() {
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
 __device__ __forceinline__ void lgkm_wait0() {
@@ -301,6 +302,23 @@ __device__ __forceinline__ void lgkm_wait0() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);   // and this position's FMAs stay below it
 }
+
+// v_mfma_f32_4x4x1 with CBSZ = 4: the A operand of block ABID (lanes 4*ABID .. 4*ABID+3) feeds all 16 blocks
+// (checked on the hardware by tools/microbench/mfma_abid.hip).  abid is a constant after unrolling; the switch folds.
+template <int ABID>
+__device__ __forceinline__ f4 mfma_abid(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, ABID, 0); }
+__device__ __forceinline__ f4 mfma_bcast(float a, float b, f4 c, int abid) {
+    switch (abid) {
+        case 0: return mfma_abid<0>(a, b, c);   case 1: return mfma_abid<1>(a, b, c);   case 2: return mfma_abid<2>(a, b, c);
+        case 3: return mfma_abid<3>(a, b, c);   case 4: return mfma_abid<4>(a, b, c);   case 5: return mfma_abid<5>(a, b, c);
+        case 6: return mfma_abid<6>(a, b, c);   case 7: return mfma_abid<7>(a, b, c);   case 8: return mfma_abid<8>(a, b, c);
+        case 9: return mfma_abid<9>(a, b, c);   case 10: return mfma_abid<10>(a, b, c); case 11: return mfma_abid<11>(a, b, c);
+        case 12: return mfma_abid<12>(a, b, c); case 13: return mfma_abid<13>(a, b, c); case 14: return mfma_abid<14>(a, b, c);
+        default: return mfma_abid<15>(a, b, c);
+    }
+}
+
+constexpr int kXSlots = kRH / 2;   // Xk ring: one slot = two region rows = 16 positions
 
 template <int GP, int AS>
 __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs a) {
@@ -358,11 +376,15 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
     const unsigned tile_bytes = a.tile_bytes;
     const unsigned row_bytes = (unsigned)a.epitch * kDF * 8;
 
-    auto issue = [&](int item, int buf) {
+    const unsigned pieces = tile_bytes >> 10;
+    auto tile_src = [&](int item) -> const char* {
         const int np = item / regions, reg = item % regions;
         const int ry = reg / a.rx, rx = reg % a.rx;
-        const char* src = a.ep + ((((size_t)np * a.nfb + fb) * a.EY + (size_t)(ry * kRH + sub_dy)) * a.EX + (size_t)(rx * kRW + sub_dx)) * (kDF * 8);
-        const unsigned pieces = tile_bytes >> 10;
+        return a.ep + ((((size_t)np * a.nfb + fb) * a.EY + (size_t)(ry * kRH + sub_dy)) * a.EX + (size_t)(rx * kRW + sub_dx)) * (kDF * 8);
+    };
+    // whole tile at once (first item; single-tile mode)
+    auto issue = [&](int item, int buf) {
+        const char* src = tile_src(item);
         for (unsigned piece = wave; piece < pieces; piece += kDWaves) {
             const unsigned b = piece * 1024 + lane * 16;
             unsigned trow = b / row_bytes;
@@ -372,43 +394,69 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
                                              (lds_ptr_t)(smem + buf * tile_bytes + piece * 1024), 16, 0, 0);
         }
     };
+    // Two-tile mode only exists for the 17 x 17 position tile of bucket R = 4 (host: nbuf == 2 <=> Rt == 4).  There every
+    // wave issues exactly kRounds4 load instructions per tile (waves without a last piece repeat their previous one), so
+    // that the counted waits of the Xk ring can step over them (see x_wait below).
+    constexpr unsigned kPieces4 = ((kRW + 2 * 4 + 1) * (kRH + 2 * 4 + 1) * kDF * 8 + 1023) / 1024;
+    constexpr int kRounds4 = (kPieces4 + kDWaves - 1) / kDWaves;
+    auto issue_next = [&](int item, int buf) {
+        const char* src = tile_src(item);
+#pragma unroll 1
+        for (int r = 0; r < kRounds4; ++r) {
+            unsigned piece = r * kDWaves + wave;
+            if (piece >= kPieces4) piece -= kDWaves;
+            const unsigned b = piece * 1024 + lane * 16;
+            unsigned trow = b / row_bytes;
+            const unsigned within = b - trow * row_bytes;
+            if (trow >= (unsigned)a.erows) trow = a.erows - 1;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)trow * a.EX * (kDF * 8) + within),
+                                             (lds_ptr_t)(smem + buf * tile_bytes + piece * 1024), 16, 0, 0);
+        }
+    };
 
-    // Xk of (item, s) at the region origin; one position = 8 floats [kind][image].  Lane l fetches the image
-    // pair of kind l%4: exactly the A operand of v_mfma_f32_4x4x1 (lane 4b+i supplies A[i]).  The address is a
-    // wave-uniform base (SGPR pair) + the per-lane kind offset (one VGPR) + an immediate: no address VALU.
+    // Xk of (item, s) at the region origin; one position = 8 floats [kind][image].  One 64-lane load fetches 16
+    // positions = two region rows: lane 4b+i gets the image pair of kind i of position b, which is the A operand of
+    // block b of v_mfma_f32_4x4x1 (lane 4b+i supplies A[i]); the MFMA of position b then broadcasts block b to all
+    // blocks (CBSZ/ABID).  512 useful bytes per load instruction -- the first version loaded one position per
+    // instruction with every quad fetching the same 32 B, which kept the texture-address unit busy half of the time
+    // (and all of the time with one unit pair per wave).  The address is a wave-uniform base (SGPR pair) + one VGPR.
     const size_t xpitch = (size_t)a.Wp * 32;
-    const unsigned xlane = (lane & 3) * 8;
+    const unsigned xlane = (unsigned)((lane >> 5) * xpitch + (lane & 31) * 8);
     auto sweep_ptr = [&](int item, int s) -> const char* {
         const int np_ = item / regions, reg_ = item % regions;
         const int ry_ = reg_ / a.rx, rx_ = reg_ % a.rx;
         return reinterpret_cast<const char*>(a.xk) +
                ((((size_t)np_ * a.s_pad + s) * a.Hp + (size_t)ry_ * kRH) * a.Wp + (size_t)rx_ * kRW) * 32;
     };
-    // Ring of the next 8 positions' Xk (2 VGPRs each), filled by ordinary vector loads and retired with
+    // Ring of the next 8 rows' Xk (4 slots of 2 VGPRs), filled by ordinary vector loads and retired with
     // COUNTED vmcnt waits: vector memory returns in order and is independent of the LDS counter.  The ring
-    // runs continuously across sweeps and items (the last row of a sweep refills it with the first row of
+    // runs continuously across sweeps and items (a finished row pair is refilled with the same rows of
     // the next sweep), so the memory latency is exposed once per kernel, not once per item.
     // (The first version fetched Xk with scalar loads: they share lgkmcnt with LDS and return out of order, so
     //  every LDS wait had to drain them; measured 6 ms of exposed scalar-miss latency.)
-    f2 xr[kRW];
+    f2 xr[kXSlots];
 #pragma unroll
-    for (int i = 0; i < kRW; ++i) xr[i] = f2{0.0f, 0.0f};
+    for (int i = 0; i < kXSlots; ++i) xr[i] = f2{0.0f, 0.0f};
     if (item0 < item1) {
         issue(item0, 0);
         const char* x0 = sweep_ptr(item0, s_of[0]);
 #pragma unroll
-        for (int i = 0; i < kRW; ++i) x_load(xr[i], xlane, x0, i * 32);
+        for (int i = 0; i < kXSlots; ++i) x_load(xr[i], xlane, x0 + 2 * i * xpitch, 0);
     }
     for (int item = item0; item < item1; ++item) {
         const bool two = a.nbuf == 2;
         const int buf = two ? (item - item0) & 1 : 0;
-        // Two tiles: the error tile of this item was requested one whole item ago, so everything but the 8 newest vector
+        // Two tiles: the error tile of this item was requested one whole item ago, so everything but the kXSlots newest vector
         // memory operations (the Xk ring) has to be complete.  One tile (it fills the LDS): it was requested after the
         // previous item's last ring refill, so everything has to be complete; that load is exposed, a few us per ~100 us item.
-        if (two) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kXSlots) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (two && item + 1 < item1 && !(a.debug & 2)) issue(item + 1, buf ^ 1);
+        // Two tiles: request the next one now (the last item re-requests its own tile into the idle buffer, so that the
+        // number of loads in flight is the same for every item).  Vector memory retires in order and these kRounds4 loads
+        // sit between the Xk ring entries: during the first sweep the counted waits allow kRounds4 more operations in
+        // flight, after that the tile has had a whole sweep of time and the waits cover it.
+        if (two) issue_next(item + 1 < item1 && !(a.debug & 2) ? item + 1 : item, buf ^ 1);
         const unsigned bufoff = buf * tile_bytes;
 #pragma unroll
         for (int si = 0; si < AS; ++si) {
@@ -416,12 +464,15 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
             // where the ring continues after this sweep: next input channel of this item, or the next item
             // (or, at the very end, the last row again so that the number of loads in flight stays constant)
             const char* xnext_sweep = si + 1 < AS ? sweep_ptr(item, s_of[si + 1 < AS ? si + 1 : si])
-                                                  : (item + 1 < item1 ? sweep_ptr(item + 1, s_of[0]) : xbase + (kRH - 1) * xpitch);
+                                                  : (item + 1 < item1 ? sweep_ptr(item + 1, s_of[0]) : xbase);
 
             // The sweep over the 8x8 region is fully unrolled (no back-edge copies).  Software pipeline over groups
             // of two positions: at the END of a group one lgkmcnt(0) retires the error columns prefetched for the
             // next group, which flew under this group's work.
-            f2 eb[2][GP][2][2];          // [buffer parity][unit pair][row: 0 = tile row j (dy=1), 1 = row j+1 (dy=0)][col]
+            // positions per group: with one unit pair per wave four positions give the same 16 packed + 8 MFMA run as two
+            // positions with two pairs (pipe switches are expensive, tools/microbench/mfma_pk_grouping)
+            constexpr int GS = GP == 1 ? 4 : 2;
+            f2 eb[2][GP][2][GS];         // [buffer parity][unit pair][row: 0 = tile row j (dy=1), 1 = row j+1 (dy=0)][col]
             f2 epn[GP][2];               // column 0 of a row (precedes its first group)
             unsigned rowaddr[GP], rowaddr2[GP];
 #pragma unroll
@@ -430,30 +481,30 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
                 rowaddr2[gp] = rowaddr[gp] + row_bytes;
                 lds_read(epn[gp][0], rowaddr[gp], 0);
                 lds_read(epn[gp][1], rowaddr2[gp], 0);
-                lds_read(eb[0][gp][0][0], rowaddr[gp], 1 * (kDF * 8));
-                lds_read(eb[0][gp][1][0], rowaddr2[gp], 1 * (kDF * 8));
-                lds_read(eb[0][gp][0][1], rowaddr[gp], 2 * (kDF * 8));
-                lds_read(eb[0][gp][1][1], rowaddr2[gp], 2 * (kDF * 8));
+#pragma unroll
+                for (int cc = 0; cc < GS; ++cc) {
+                    lds_read(eb[0][gp][0][cc], rowaddr[gp], (1 + cc) * (kDF * 8));
+                    lds_read(eb[0][gp][1][cc], rowaddr2[gp], (1 + cc) * (kDF * 8));
+                }
             }
             lgkm_wait0();
 #pragma unroll
             for (int j = 0; j < kRH; ++j) {
-                const char* xreload = j + 1 < kRH ? xbase + (j + 1) * xpitch : xnext_sweep;   // row refilling the ring
 #pragma unroll
-                for (int gq = 0; gq < kRW / 2; ++gq) {
-                    constexpr int kGroups = kRW / 2;
+                for (int gq = 0; gq < kRW / GS; ++gq) {
+                    constexpr int kGroups = kRW / GS;
                     const int par = gq & 1;
-                    // Prefetch the following group's error columns into the other buffer.  That buffer's SECOND column is still
-                    // needed (as the left neighbour) by this group's first position, so only the first column is requested
-                    // now; the second follows after position 0 (prefetch_col<1> below).
+                    // Prefetch the following group's error columns into the other buffer.  That buffer's LAST column is still
+                    // needed (as the left neighbour) by this group's first position, so it is requested only after the
+                    // interpolation blocks; the others go out now.
 #define DAU_PREFETCH_COL(col)                                                                                       \
     if (gq + 1 < kGroups) {                                                                                         \
         _Pragma("unroll") for (int gp = 0; gp < GP; ++gp) {                                                         \
-            lds_read(eb[par ^ 1][gp][0][col], rowaddr[gp], (2 * gq + 3 + col) * (kDF * 8));                         \
-            lds_read(eb[par ^ 1][gp][1][col], rowaddr2[gp], (2 * gq + 3 + col) * (kDF * 8));                        \
+            lds_read(eb[par ^ 1][gp][0][col], rowaddr[gp], (GS * gq + GS + 1 + col) * (kDF * 8));                   \
+            lds_read(eb[par ^ 1][gp][1][col], rowaddr2[gp], (GS * gq + GS + 1 + col) * (kDF * 8));                  \
         }                                                                                                           \
     } else if (j + 1 < kRH) {                                                                                       \
-        /* first group of the next row: tile rows j+1 and j+2 (rowaddr2 / rowaddr2 + pitch), columns 0..2 */        \
+        /* first group of the next row: tile rows j+1 and j+2 (rowaddr2 / rowaddr2 + pitch), columns 0..GS */       \
         _Pragma("unroll") for (int gp = 0; gp < GP; ++gp) {                                                         \
             const unsigned r3 = rowaddr2[gp] + row_bytes;                                                           \
             if (col == 0) {                                                                                         \
@@ -464,19 +515,20 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
             lds_read(eb[par ^ 1][gp][1][col], r3, (1 + col) * (kDF * 8));                                           \
         }                                                                                                           \
     }
-                    DAU_PREFETCH_COL(0)
-                    // The group's two positions x GP unit pairs = 2*GP elements: first ALL interpolation blocks (8*GP packed
-                    // ops), then ALL kind-contractions (4*GP MFMAs).  Alternating the packed-VALU and MFMA pipes in small
-                    // groups is slow on gfx950 (tools/microbench/mfma_pk_grouping: 2 MFMA + 4 pk per switch 125 TF, 8 + 16: 143 TF).
-                    f2 et[2][GP];
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) {
+                    for (int cc = 0; cc + 1 < GS; ++cc) { DAU_PREFETCH_COL(cc) }
+                    // The group's GS positions x GP unit pairs: first ALL interpolation blocks (16 packed ops), then ALL
+                    // kind-contractions (8 MFMAs).  Alternating the packed-VALU and MFMA pipes in small groups is slow on
+                    // gfx950 (tools/microbench/mfma_pk_grouping: 2 MFMA + 4 pk per switch 125 TF, 8 + 16: 143 TF).
+                    f2 et[GS][GP];
+#pragma unroll
+                    for (int p = 0; p < GS; ++p) {
 #pragma unroll
                         for (int gp = 0; gp < GP; ++gp) {
                             const f2 e1 = eb[par][gp][0][p], e0 = eb[par][gp][1][p];
-                            // column to the left: the row's column 0, the previous group's second column, or this group's first
-                            const f2 l1 = p == 1 ? eb[par][gp][0][0] : (gq == 0 ? epn[gp][0] : eb[par ^ 1][gp][0][1]);
-                            const f2 l0 = p == 1 ? eb[par][gp][1][0] : (gq == 0 ? epn[gp][1] : eb[par ^ 1][gp][1][1]);
+                            // column to the left: this group's previous column, the row's column 0, or the previous group's last
+                            const f2 l1 = p > 0 ? eb[par][gp][0][p > 0 ? p - 1 : 0] : (gq == 0 ? epn[gp][0] : eb[par ^ 1][gp][0][GS - 1]);
+                            const f2 l0 = p > 0 ? eb[par][gp][1][p > 0 ? p - 1 : 0] : (gq == 0 ? epn[gp][1] : eb[par ^ 1][gp][1][GS - 1]);
                             // Et = b00*E[q-o] + b01*E[q-o-(0,1)] + b10*E[q-o-(1,0)] + b11*E[q-o-(1,1)]; every dependency is
                             // through the accumulator operand, which needs no wait state
                             asm volatile("v_pk_mul_f32 %0, %1, %5 op_sel_hi:[1,0]\n\t"
@@ -488,21 +540,25 @@ __global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs 
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    // the other buffer's second column (left neighbour of this group's first position) is now consumed
-                    { DAU_PREFETCH_COL(1) }
-                    x_wait6();      // Xk of both positions of the group
+                    // the other buffer's last column (left neighbour of this group's first position) is now consumed
+                    { DAU_PREFETCH_COL(GS - 1) }
+                    // Xk of this row pair: its slot is the oldest of the ring
+                    if (j % 2 == 0 && gq == 0) {
+                        if (si == 0 && two) x_wait<kXSlots - 1 + kRounds4>();
+                        else x_wait<kXSlots - 1>();
+                    }
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) {
+                    for (int p = 0; p < GS; ++p) {
 #pragma unroll
                         for (int gp = 0; gp < GP; ++gp) {
-                            acc[si][gp][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(xr[2 * gq + p].x, et[p][gp].x, acc[si][gp][0], 0, 0, 0);
-                            acc[si][gp][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(xr[2 * gq + p].y, et[p][gp].y, acc[si][gp][1], 0, 0, 0);
+                            const int abid = (j & 1) * kRW + GS * gq + p;     // position within the slot's 16
+                            acc[si][gp][0] = mfma_bcast(xr[j / 2].x, et[p][gp].x, acc[si][gp][0], abid);
+                            acc[si][gp][1] = mfma_bcast(xr[j / 2].y, et[p][gp].y, acc[si][gp][1], abid);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    // both ring slots are consumed: refill them with the next row (or the next sweep's first row)
-                    x_load(xr[2 * gq], xlane, xreload, (2 * gq) * 32);
-                    x_load(xr[2 * gq + 1], xlane, xreload, (2 * gq + 1) * 32);
+                    // the row pair is consumed: refill its slot with the same rows of the next sweep
+                    if (j % 2 == 1 && gq + 1 == kGroups) x_load(xr[j / 2], xlane, xnext_sweep + (j - 1) * xpitch, 0);
                     lgkm_wait0();   // the prefetched group has landed
                 }
                 // next row: tile rows shift down by one
