@@ -42,8 +42,11 @@ WORKLOADS = {
     # configs[3]: per-GPU share of the N=1024 batch-sharded step
     "c3": dict(N=128, S=512, F=512, H=28, W=28, G=4, k=9, m=3.0,
                label="batch-sharded step N=128/GPU C=512->512 HW=28 G=4 k=9 fp32 fwd+bwd"),
-    # configs[4]: segmentation-scale maps, nine units, offsets up to +-16 (max_kernel_size 33)
-    "c4": dict(N=16, S=256, F=256, H=512, W=512, G=9, k=33, m=15.0,
+    # configs[4]: segmentation-scale maps, nine units, offsets up to +-17 => offset bucket 32 (max_kernel_size 65)
+    "c4": dict(N=16, S=256, F=256, H=512, W=512, G=9, k=65, m=17.0,
+               label="seg-scale N=16/GPU C=256->256 HW=512 G=9 k=65 mu~U(-17,17) fp32 fwd+bwd"),
+    # the same maps with offsets within +-16 (bucket 16, max_kernel_size 33)
+    "c4k33": dict(N=16, S=256, F=256, H=512, W=512, G=9, k=33, m=15.0,
                label="seg-scale N=16/GPU C=256->256 HW=512 G=9 k=33 mu~U(-15,15) fp32 fwd+bwd"),
     "small": dict(N=8, S=32, F=32, H=56, W=56, G=4, k=9, m=3.0, label="smoke-size N=8 C=32->32 HW=56 G=4"),
 }

@@ -296,9 +296,11 @@ int dau_conv_forward(const dau_conv_plan* p, void* stream, const float* x, const
     launch_synth_filters(st, sigma, p->blur_k, p->d.flags, ws.filters);
     launch_prepare_units(st, w, mu1, mu2, s, p->d.number_units_ignore, p->d.flags, p->bucket, false, ws.table, ws.status);
     if (p->algo_fwd == DAU_ALGO_TILED) {
-        tiled_gather_prepare(st, p->tiled_fwd, x, ws.filters, false, ws.table, ws.tiled);
-        ProfScope prof(p, 0, st);
-        tiled_gather_run(st, p->tiled_fwd, y, ws.tiled);
+        for (int window = 0; window < tiled_gather_windows(p->tiled_fwd); ++window) {   // one pass unless the bucket is 32
+            tiled_gather_prepare(st, p->tiled_fwd, x, ws.filters, false, ws.table, ws.tiled, window);
+            ProfScope prof(p, 0, st);
+            tiled_gather_run(st, p->tiled_fwd, y, ws.tiled, window > 0);
+        }
     } else {
         launch_blur_direct(st, x, (long)s.N * s.S, s.H, s.W, ws.filters + 0 * kFilterPlane, 1, p->blur_k, ws.xb);
         ProfScope prof(p, 0, st);
@@ -349,9 +351,11 @@ int dau_conv_backward(const dau_conv_plan* p, void* stream, const float* x, cons
         launch_prepare_units(st, w, mu1, mu2, s, 0, flags, p->bucket, true, ws.table_t,
                              (need_mask & param_mask) ? nullptr : ws.status);
         if (p->algo_fwd == DAU_ALGO_TILED) {
-            tiled_gather_prepare(st, p->tiled_dx, dy, ws.filters, true, ws.table_t, ws.tiled_dx);
-            ProfScope prof(p, 1, st);
-            tiled_gather_run(st, p->tiled_dx, dx, ws.tiled_dx);
+            for (int window = 0; window < tiled_gather_windows(p->tiled_dx); ++window) {
+                tiled_gather_prepare(st, p->tiled_dx, dy, ws.filters, true, ws.table_t, ws.tiled_dx, window);
+                ProfScope prof(p, 1, st);
+                tiled_gather_run(st, p->tiled_dx, dx, ws.tiled_dx, window > 0);
+            }
         } else {
             launch_blur_direct(st, dy, (long)s.N * s.F, s.H, s.W, ws.filters + 5 * kFilterPlane, 1, p->blur_k, ws.eb);
             ProfScope prof(p, 1, st);

@@ -13,6 +13,7 @@ struct TiledConfig {
     int R;            // offset bucket
     int blur_k;       // prefilter support
     int NP;           // image pairs = ceil(N/2)
+    int windows;      // gather passes: 1, or 4 offset windows of radius 16 for bucket 32
     int stack;        // (image pair, patch) planes gathered per workgroup
     int patches;      // patches per image: big or odd-sized images are gathered patch by patch
     int rows, pitch;  // staged plane of a patch: rows = ph + 2R + 1, pitch (in positions) >= pw + 2R + 1 with pitch % 32 == 8
@@ -26,9 +27,11 @@ size_t tiled_gather_workspace_bytes(const TiledConfig& cfg);
 // prepare: blur `in` ([N,Cin,H,W]) with the Gaussian (`filters` = output of launch_synth_filters; `mirrored`
 // selects the flipped kernel of the input-gradient pass) into the staged pair-interleaved planes and pack the
 // unit table (`table` is indexed [Cin][G][Cout]).  run: the gather itself, writing `out` ([N,Cout,H,W]).
+int tiled_gather_windows(const TiledConfig& cfg);
+// one pass per offset window: prepare(window) then run(accumulate = window > 0)
 void tiled_gather_prepare(hipStream_t st, const TiledConfig& cfg, const float* in, const float* filters, bool mirrored,
-                          const UnitRef* table, void* workspace);
-void tiled_gather_run(hipStream_t st, const TiledConfig& cfg, float* out, void* workspace);
+                          const UnitRef* table, void* workspace, int window);
+void tiled_gather_run(hipStream_t st, const TiledConfig& cfg, float* out, void* workspace, bool accumulate);
 
 struct TiledDotConfig {
     Shape sh;

@@ -41,7 +41,10 @@ namespace {
 
 constexpr int kDF = 32;        // output channels per workgroup (half a wave; the two halves are two units g)
 constexpr int kRW = 8, kRH = 8;  // region of positions q handled per item
-constexpr int kDWaves = 16;
+#ifndef DAU_DOT_WAVES
+#define DAU_DOT_WAVES 16
+#endif
+constexpr int kDWaves = DAU_DOT_WAVES;
 constexpr int kParamDwords = 8;  // per lane per (s, g-pair): b00,b01,b10,b11, base, pad x3
 
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -90,6 +93,7 @@ DotGeometry make_dot_geometry(const Shape& sh, int R) {
     g.chunks = chunks;
     g.tile_bytes = round_up((size_t)g.erows * g.epitch * kDF * 8, 1024);
     g.nbuf = 2 * g.tile_bytes <= 160 * 1024 ? 2 : 1;
+    if (getenv("DAU_DOT_NBUF") && atoi(getenv("DAU_DOT_NBUF")) == 1) g.nbuf = 1;   // timing experiments
     return g;
 }
 
@@ -321,7 +325,7 @@ __device__ __forceinline__ f4 mfma_bcast(float a, float b, f4 c, int abid) {
 constexpr int kXSlots = kRH / 2;   // Xk ring: one slot = two region rows = 16 positions
 
 template <int GP, int AS>
-__global__ void __launch_bounds__(kDWaves * 64) gather_dot_kernel(const DotArgs a) {
+__global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) gather_dot_kernel(const DotArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -48,6 +48,9 @@ inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // image are computed and dropped at the store); the one non-EDGE variant covers a whole 25..31 pixel image.
 struct Geometry {
     int H, W, R;              // image, offset bucket
+    int Rt;                   // offset radius one staged plane covers: min(R, 16)
+    int nwin1;                // R = 32: the offset range is cut into nwin1 x nwin1 windows of radius Rt, one gather pass per
+                              // window (shifted planes, units outside the window carry zero weights), outputs accumulate
     int ph, pw;               // patch (pixels)
     int npx, npy;             // patches per image
     int rows, pitch, cols;    // staged plane of one patch: rows x pitch positions, the first `cols` columns carry data
@@ -92,6 +95,8 @@ size_t ut_stride_bytes(int G, int fb) { return round_up((size_t)G * fb * kUnitDw
 Geometry make_geometry(int H, int W, int R, int G, int N, int Cout, int only = -1) {
     Geometry g{};
     g.H = H; g.W = W; g.R = R; g.variant = -1;
+    g.Rt = R > 16 ? 16 : R; g.nwin1 = R / g.Rt;
+    R = g.Rt;                                                // everything below sizes ONE plane
     const char* split_env = getenv("DAU_GATHER_SPLIT");      // tuning knob: waves per output channel
     const int want_split = split_env ? atoi(split_env) : 0;
     // DAU_GATHER_VARIANT=<row> at plan creation pins the kernel (tests of the small-map variants on small batches)
@@ -153,6 +158,7 @@ struct BlurPackArgs {
     const float* taps;
     float* staged;
     int mirrored, N, C, H, W, R, k;
+    int cy, cx;                 // offset-window centre (0 unless the bucket is cut into windows)
     int ph, pw, npx, npy;
     int rows, pitch, cols, strip_cols;
     size_t plane_floats;
@@ -167,7 +173,7 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
     const int npp = blockIdx.x / C;                // (image pair, patch)
     const int npatch = a.npx * a.npy;
     const int np = npp / npatch, patch = npp % npatch;
-    const int wy0 = (patch / a.npx) * a.ph - R, wx0 = (patch % a.npx) * a.pw - R;   // image coordinates of staged (0, 0)
+    const int wy0 = (patch / a.npx) * a.ph - R + a.cy, wx0 = (patch % a.npx) * a.pw - R + a.cx;   // image coordinates of staged (0, 0)
     // the part of the window that lies inside the image
     const int ya0 = wy0 > 0 ? wy0 : 0, ya1 = wy0 + a.rows < H ? wy0 + a.rows : H;
     const int xa0 = wx0 > 0 ? wx0 : 0, xa1 = wx0 + a.cols < W ? wx0 + a.cols : W;
@@ -237,8 +243,10 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
 // ------------------------------------------------------------------------------------------------
 // unit packing: UnitRef[Cin][G][Cout] -> packed[FBn][Cin] slices of [G][kFB][8 dwords], each slice padded to 1 KiB
 // ------------------------------------------------------------------------------------------------
-__global__ void pack_units_kernel(const UnitRef* __restrict__ table, int Cin, int G, int Cout, int pitch, int R,
-                                  int strip_pitch, int ut_stride_dwords, int kFB, unsigned int* __restrict__ packed) {
+// R: offset bucket; Rt, nwin1, window: the pass's offset window (Rt == R, nwin1 == 1: the whole bucket)
+__global__ void pack_units_kernel(const UnitRef* __restrict__ table, int Cin, int G, int Cout, int pitch, int R, int Rt,
+                                  int nwin1, int window, int strip_pitch, int ut_stride_dwords, int kFB,
+                                  unsigned int* __restrict__ packed) {
     const int nfb = (Cout + kFB - 1) / kFB;
     const long total = (long)nfb * Cin * G * kFB;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -249,8 +257,14 @@ __global__ void pack_units_kernel(const UnitRef* __restrict__ table, int Cin, in
         const int f = fb * kFB + fi;
         UnitRef u{0, 0, 0.0f, 0.0f, 0.0f, 0.0f};
         if (f < Cout) u = table[((long)c * G + g) * Cout + f];
-        const int off = (u.oy * pitch + u.ox) * 8;   // byte displacement inside a staged plane
-        const int offt = ((u.ox + R) * strip_pitch + u.oy) * 8;   // ... and inside its transposed strip
+        // a unit belongs to exactly one offset window; in the other passes it contributes nothing
+        int wy = (u.oy + R) / (2 * Rt), wx = (u.ox + R) / (2 * Rt);
+        wy = wy < nwin1 ? wy : nwin1 - 1; wx = wx < nwin1 ? wx : nwin1 - 1;
+        const int cy = -R + Rt + 2 * Rt * (window / nwin1), cx = -R + Rt + 2 * Rt * (window % nwin1);
+        if (wy != window / nwin1 || wx != window % nwin1) u = UnitRef{cx, cy, 0.0f, 0.0f, 0.0f, 0.0f};
+        const int ox = u.ox - cx, oy = u.oy - cy;    // displacement relative to the window centre, |.| <= Rt
+        const int off = (oy * pitch + ox) * 8;       // byte displacement inside a staged plane
+        const int offt = ((ox + Rt) * strip_pitch + oy) * 8;   // ... and inside its transposed strip
         unsigned int* dst = packed + ((long)fb * Cin + c) * ut_stride_dwords + (g * kFB + fi) * kUnitDwords;
         dst[0] = __float_as_uint(u.w00); dst[1] = (unsigned)off;
         dst[2] = __float_as_uint(u.w01); dst[3] = (unsigned)off;
@@ -272,6 +286,7 @@ struct GatherArgs {
     unsigned plane_bytes, ut_stride;
     unsigned strip_off;        // byte offset of the transposed strip inside a plane
     unsigned zpitch;           // epilogue Z-plane pitch (floats)
+    int accumulate;            // 1: add to out (second and later offset-window passes)
     int debug;                 // timing experiments only (DAU_GATHER_DEBUG): 1 = no plane refills after the first two
 };
 
@@ -527,8 +542,10 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
                 const int gy = (patch / a.npx) * H + y, gx = (patch % a.npx) * W + x;    // non-EDGE: one patch, origin 0
                 const float* zf = zs + (size_t)kf * zchan + (unsigned)y * zpitch + x;
                 const float v = zf[0] + zf[zplane + 1] + zf[2 * zplane + zpitch] + zf[3 * zplane + zpitch + 1];
-                if (npp < npp_total && n < a.N && f < a.Cout && gy < a.H && gx < a.W)
-                    a.out[((long)n * a.Cout + f) * plane_out + (long)gy * a.W + gx] = v;
+                if (npp < npp_total && n < a.N && f < a.Cout && gy < a.H && gx < a.W) {
+                    float* dst = a.out + ((long)n * a.Cout + f) * plane_out + (long)gy * a.W + gx;
+                    *dst = a.accumulate ? *dst + v : v;
+                }
             }
         }
     }
@@ -585,7 +602,7 @@ bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R
     c.N = N; c.Cin = Cin; c.Cout = Cout; c.G = G; c.H = H; c.W = W; c.R = R; c.blur_k = blur_k;
     c.NP = (N + 1) / 2;
     c.rows = g.rows; c.pitch = g.pitch; c.tiles_x = g.tx; c.tiles_y = g.ty; c.fblock = g.fb; c.variant = g.variant;
-    c.patches = g.npx * g.npy; c.stack = g.sk;
+    c.patches = g.npx * g.npy; c.stack = g.sk; c.windows = g.nwin1 * g.nwin1;
     if (lds_bytes(c, g) > 160 * 1024) return false;
     // blur_pack keeps both raw planes (+ blur halo) and the horizontally filtered rows in LDS
     if (blur_pack_lds_bytes(g, blur_k) > 150 * 1024) return false;
@@ -599,8 +616,10 @@ size_t tiled_gather_workspace_bytes(const TiledConfig& c) {
     return round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256) + round_up(nfb * c.Cin * ut_stride_bytes(c.G, g.fb), 256);
 }
 
+int tiled_gather_windows(const TiledConfig& c) { return c.windows; }
+
 void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in, const float* filters, bool mirrored,
-                          const UnitRef* table, void* workspace) {
+                          const UnitRef* table, void* workspace, int window) {
     const Geometry g = make_geometry(c.H, c.W, c.R, c.G, c.N, c.Cout, c.variant);
     char* staged = static_cast<char*>(workspace);
     char* packed = staged + round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256);
@@ -610,9 +629,12 @@ void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in,
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     BlurPackArgs b{};
     b.in = in; b.taps = filters + kTaps1dOffset; b.staged = reinterpret_cast<float*>(staged);
-    b.mirrored = mirrored ? 1 : 0; b.N = c.N; b.C = c.Cin; b.H = c.H; b.W = c.W; b.R = c.R; b.k = c.blur_k;
+    // centre of this pass's offset window: staged (row, col) of a patch is the image at (py*ph - Rt + cy + row, ...)
+    const int cy = -c.R + g.Rt + 2 * g.Rt * (window / g.nwin1), cx = -c.R + g.Rt + 2 * g.Rt * (window % g.nwin1);
+    b.mirrored = mirrored ? 1 : 0; b.N = c.N; b.C = c.Cin; b.H = c.H; b.W = c.W; b.R = g.Rt; b.k = c.blur_k;
+    b.cy = cy; b.cx = cx;
     b.ph = g.ph; b.pw = g.pw; b.npx = g.npx; b.npy = g.npy;
-    b.rows = g.rows; b.pitch = g.pitch; b.cols = g.cols; b.strip_cols = g.edge ? 2 * c.R + 1 : 0;
+    b.rows = g.rows; b.pitch = g.pitch; b.cols = g.cols; b.strip_cols = g.edge ? 2 * g.Rt + 1 : 0;
     b.plane_floats = g.plane_bytes / 4;
     hipLaunchKernelGGL(kern, dim3(c.NP * c.patches * c.Cin), dim3(512), blur_lds, st, b);
     const int nfb = (c.Cout + g.fb - 1) / g.fb;
@@ -621,19 +643,21 @@ void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in,
     (void)hipMemsetAsync(packed, 0, (size_t)nfb * c.Cin * uts, st);
     const long total = (long)nfb * c.Cin * c.G * g.fb;
     const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-    hipLaunchKernelGGL(pack_units_kernel, dim3(grid), dim3(256), 0, st, table, c.Cin, c.G, c.Cout, g.pitch, c.R, g.strip_pitch,
+    hipLaunchKernelGGL(pack_units_kernel, dim3(grid), dim3(256), 0, st, table, c.Cin, c.G, c.Cout, g.pitch, c.R, g.Rt, g.nwin1,
+                       window, g.strip_pitch,
                        (int)(uts / 4), g.fb,
                        reinterpret_cast<unsigned int*>(packed));
 }
 
-void tiled_gather_run(hipStream_t st, const TiledConfig& c, float* out, void* workspace) {
+void tiled_gather_run(hipStream_t st, const TiledConfig& c, float* out, void* workspace, bool accumulate) {
     const Geometry g = make_geometry(c.H, c.W, c.R, c.G, c.N, c.Cout, c.variant);
     GatherArgs a{};
     a.staged = static_cast<const char*>(workspace);
     a.packed = a.staged + round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256);
     a.out = out;
     a.npx = g.npx; a.npy = g.npy;
-    a.N = c.N; a.Cin = c.Cin; a.Cout = c.Cout; a.G = c.G; a.H = c.H; a.W = c.W; a.R = c.R;
+    a.N = c.N; a.Cin = c.Cin; a.Cout = c.Cout; a.G = c.G; a.H = c.H; a.W = c.W; a.R = g.Rt;
+    a.accumulate = accumulate ? 1 : 0;
     a.nfb = (c.Cout + g.fb - 1) / g.fb;
     a.plane_bytes = (unsigned)g.plane_bytes;
     a.strip_off = (unsigned)g.strip_off;

@@ -65,7 +65,9 @@ def test_tiled_kernels_are_selected_for_benchmark_shapes():
     for (H, W, k) in ((56, 56, 9), (32, 32, 9), (32, 32, 17), (16, 16, 9), (8, 8, 9), (27, 27, 9), (28, 28, 9), (24, 24, 9),
                       # patch decomposition: feature maps of ResNet / CIFAR stages, odd sizes, large images, kernels 17 and 33
                       (14, 14, 9), (7, 7, 9), (64, 64, 9), (112, 112, 9), (8, 65, 9), (90, 100, 9), (224, 224, 9), (56, 56, 17),
-                      (64, 64, 33), (128, 96, 17), (512, 512, 33)):
+                      (64, 64, 33), (128, 96, 17), (512, 512, 33),
+                      # kernel 65: four offset-window passes of the kernel-33 gather
+                      (64, 64, 65), (40, 100, 65)):
         info = _capi.Plan(2, 4, 8, 2, H, W, max_kernel_size=k).info
         assert info["algo_forward"] == _capi.ALGO_TILED, (H, W, k, info)
     # gather-dot: any image size, any unit count, kernels 9 and 17
