@@ -79,8 +79,8 @@ const Variant kVariants[] = {
     // the smallest, more output channels per workgroup so that a staged plane is fetched from L2 less often per MFMA.
     {4, 4, 72, 1, 2, 2, 26624, 4, 0},   // 8: 2 x 32x32 patches
     {3, 3, 40, 1, 2, 4, 13312, 4, 0},   // 9: 4 x 24x24
-    {2, 2, 40, 1, 1, 3, 10240, 8, 0},   // 10: 3 x 16x16, 8 channels
-    {1, 1, 40, 1, 1, 3, 7168, 16, 0},   // 11: 3 x 8x8, 16 channels
+    {2, 2, 40, 1, 1, 4, 10240, 8, 0},   // 10: 4 x 16x16, 8 channels
+    {1, 1, 40, 1, 1, 4, 7168, 16, 0},   // 11: 4 x 8x8, 16 channels
     {4, 4, 40, 0, 2, 3, 13312, 4, 0},   // 12: 3 x one 25..31 pixel image
     // whole images of at most 23 / 15 / 7 pixels: the (H+1) x (W+1) domain of Z fits the regular tiles, no edge tiles
     {3, 3, 40, 0, 1, 2, 10240, 8, 0},   // 13: 2 x one 17..23 pixel image, 8 channels
@@ -129,7 +129,8 @@ Geometry make_geometry(int H, int W, int R, int G, int N, int Cout, int only = -
         // relative cost in tile units: MFMA tiles + the DMA of the planes + a fixed part per workgroup and channel
         // (barrier, unit fetch, exposed LDS latency: ~12 tiles' worth, fitted to 28x28 stacked vs plain)
         // (per four output channels: a workgroup with more channels fetches its planes and pays its barriers once for all)
-        double cost = (double)groups * (v.sk * (v.tx * v.ty + (v.edge ? 2 : 0) + 0.02 * rows * v.pitch / 8.0 * (4.0 / v.fb)) + 12.0 * (4.0 / v.fb));
+        const int edge_tiles = v.edge ? ((v.tx + v.ty) * 8 + 1 <= 64 ? 1 : 2) : 0;
+        double cost = (double)groups * (v.sk * (v.tx * v.ty + edge_tiles + 0.02 * rows * v.pitch / 8.0 * (4.0 / v.fb)) + 12.0 * (4.0 / v.fb));
         // a grid that ends with a nearly empty round of workgroups wastes the chip: price the rounds, not the blocks
         cost *= (double)((blocks + 255) / 256 * 256) / (double)blocks;
         if (v.tuning && only < 0) cost = 0.0;                // explicitly requested
@@ -301,7 +302,9 @@ struct GatherTraits {
     static constexpr int TX = TX_, TY = TY_, PITCH = PITCH_, SPLIT = SPLIT_, SK = SK_, PB = PB_, FB = FB_;
     static constexpr bool EDGE = EDGE_;
     static constexpr int kRegular = TX * TY;
-    static constexpr int kPlaneTiles = kRegular + (EDGE ? 2 : 0);
+    // the extra row and column of Z share one tile when they fit its 64 lanes (patches up to 24 pixels)
+    static constexpr bool kMergeEdge = EDGE && (TX * 8 + TY * 8 + 1 <= 64);
+    static constexpr int kPlaneTiles = kRegular + (EDGE ? (kMergeEdge ? 1 : 2) : 0);
     static constexpr int kTiles = SK * kPlaneTiles;
     static constexpr int kPerPart = (kTiles + SPLIT - 1) / SPLIT;
     static constexpr int kWaves = FB * SPLIT;
@@ -405,7 +408,13 @@ __device__ __forceinline__ void unit_group(f4 (&acc)[KP][2], unsigned ut_addr, u
             const unsigned oraw = __float_as_uint(wo[u].y);
             const unsigned off = (unsigned)__builtin_amdgcn_mov_dpp((int)oraw, 0x00, 0xf, 0xf, true) + pbase;
             const unsigned offt = (unsigned)__builtin_amdgcn_mov_dpp((int)oraw, 0xAA, 0xf, 0xf, true) + pbase;
-            addr[u] = lane_base + off; addr_e0[u] = ebase0 + off; addr_e1[u] = ebase1 + offt;
+            addr[u] = lane_base + off;
+            if constexpr (T::kMergeEdge) {
+                // one edge tile: ebase1 is a lane mask, set for the lanes that walk the column strip
+                addr_e0[u] = ebase0 + ((off & ~ebase1) | (offt & ebase1)); addr_e1[u] = 0;
+            } else {
+                addr_e0[u] = ebase0 + off; addr_e1[u] = ebase1 + offt;
+            }
         }
         f2 xv[2][kBatch];
         load_batch<T, first, count, 0>(xv[0], addr[0], addr_e0[0], addr_e1[0], std::make_integer_sequence<int, kBatch>{});
@@ -444,12 +453,22 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
     // made LDS, not the matrix pipe, the busiest resource).
     int ey[2] = {0, 0}, ex[2] = {0, 0};
     bool evalid[2] = {false, false};
-    if (EDGE) {
-        if (lane < W) { ey[0] = H; ex[0] = lane; evalid[0] = true; }
-        if (lane <= H) { ey[1] = lane; ex[1] = W; evalid[1] = true; }
+    unsigned ebase0, ebase1;
+    if (T::kMergeEdge) {
+        // lanes 0..W-1: the row y = H; lanes W..W+H: the column x = W (from the strip); ebase1 = mask of the latter
+        const bool col = lane >= W;
+        if (!col) { ey[0] = H; ex[0] = lane; evalid[0] = true; }
+        else if (lane <= W + H) { ey[0] = lane - W; ex[0] = W; evalid[0] = true; }
+        ebase0 = col ? (unsigned)(a.strip_off + (ey[0] + R) * 8) : (unsigned)(((ey[0] + R) * PITCH + ex[0] + R) * 8);
+        ebase1 = col ? 0xffffffffu : 0u;
+    } else {
+        if (EDGE) {
+            if (lane < W) { ey[0] = H; ex[0] = lane; evalid[0] = true; }
+            if (lane <= H) { ey[1] = lane; ex[1] = W; evalid[1] = true; }
+        }
+        ebase0 = (unsigned)(((ey[0] + R) * PITCH + ex[0] + R) * 8);
+        ebase1 = (unsigned)(a.strip_off + (ey[1] + R) * 8);
     }
-    const unsigned ebase0 = (unsigned)(((ey[0] + R) * PITCH + ex[0] + R) * 8);
-    const unsigned ebase1 = (unsigned)(a.strip_off + (ey[1] + R) * 8);
 
     const unsigned plane_bytes = T::PB ? (unsigned)T::PB : a.plane_bytes, ut_stride = a.ut_stride;
     const unsigned buf_bytes = SK * plane_bytes;
@@ -677,8 +696,8 @@ void tiled_gather_run(hipStream_t st, const TiledConfig& c, float* out, void* wo
         case 7: launch_variant<GatherTraits<7, 7, 72, true, 3>>(st, a, grid, lds); break;
         case 8: launch_variant<GatherTraits<4, 4, 72, true, 2, 2, 26624>>(st, a, grid, lds); break;
         case 9: launch_variant<GatherTraits<3, 3, 40, true, 2, 4, 13312>>(st, a, grid, lds); break;
-        case 10: launch_variant<GatherTraits<2, 2, 40, true, 1, 3, 10240, 8>>(st, a, grid, lds); break;
-        case 11: launch_variant<GatherTraits<1, 1, 40, true, 1, 3, 7168, 16>>(st, a, grid, lds); break;
+        case 10: launch_variant<GatherTraits<2, 2, 40, true, 1, 4, 10240, 8>>(st, a, grid, lds); break;
+        case 11: launch_variant<GatherTraits<1, 1, 40, true, 1, 4, 7168, 16>>(st, a, grid, lds); break;
         case 12: launch_variant<GatherTraits<4, 4, 40, false, 2, 3, 13312>>(st, a, grid, lds); break;
         case 13: launch_variant<GatherTraits<3, 3, 40, false, 1, 2, 10240, 8>>(st, a, grid, lds); break;
         case 14: launch_variant<GatherTraits<2, 2, 40, false, 1, 4, 8192, 8>>(st, a, grid, lds); break;

@@ -221,8 +221,8 @@ def test_seeded_shapes_against_c_oracle(shape, algo):
     # group is short (planes % stack != 0) and N is odd (zero image in the last pair)
     dict(N=5, W=32, H=32, S=5, F=12, G=4, k=9, m=3, variant=8, stack=2, patch=32),
     dict(N=7, W=24, H=24, S=4, F=8, G=2, k=9, m=3, variant=9, stack=4, patch=24),
-    dict(N=9, W=16, H=16, S=6, F=10, G=3, k=9, m=3, variant=10, stack=3, patch=16),    # 8 channels per workgroup
-    dict(N=21, W=8, H=8, S=8, F=20, G=4, k=9, m=3, variant=11, stack=3, patch=8),      # 16 channels per workgroup
+    dict(N=9, W=16, H=16, S=6, F=10, G=3, k=9, m=3, variant=10, stack=4, patch=16),    # 8 channels per workgroup
+    dict(N=21, W=8, H=8, S=8, F=20, G=4, k=9, m=3, variant=11, stack=4, patch=8),      # 16 channels per workgroup
     dict(N=7, W=28, H=28, S=5, F=8, G=4, k=9, m=3, variant=12, stack=3, patch=32),     # whole 28x28 images
     dict(N=3, W=27, H=27, S=3, F=8, G=6, k=9, m=3, variant=12, stack=3, patch=32),
     dict(N=3, W=40, H=20, S=3, F=8, G=4, k=9, m=3, variant=9, stack=4, patch=24),      # two patch columns, stacked across patches and pairs
