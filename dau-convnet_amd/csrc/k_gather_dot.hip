@@ -11,18 +11,21 @@
 //        r_k[u] = sum_{n,q} Xk[n,s,q] * Et_u[n,f,q],   Et_u[q] = sum_{dy,dx} b_{dy,dx} E'[q - o_u - (dy,dx)]
 //    so the error is interpolated once (4 MACs) and multiplied by the four k-planes (4 MACs): 8 MACs
 //    per (n, q, unit), the minimum (dau_conv_backward_core.hpp:846-975 does the same split).
-//  * LANE = UNIT.  A wave owns one input channel s and one pair of units g; its 64 lanes are the two
-//    units x 32 output channels.  Every lane keeps its own four accumulators for the whole kernel, so
-//    there is no cross-lane reduction (the reference needs cub::WarpReduce + atomics, :1747-1811).
-//  * The position q is wave-uniform: Xk[n,s,q] (4 kinds x 2 images = 32 B) arrives by SCALAR loads and
-//    feeds v_pk_fma_f32 as an SGPR pair; the error tile sits in LDS position-major with the 32 output
-//    channels fastest ([row][col][f][image]), so lane f always hits bank pair f: conflict-free
-//    ds_read_b64 at ANY per-lane displacement.
-//  * Two images are interleaved element-wise, so every packed FMA operand is a natural register pair
-//    (image n, image n+1); the bilinear factors are broadcast with op_sel.  8 v_pk_fma_f32 per position.
-//  * A workgroup owns (32 output channels, a block of input channels) and walks (image pair, 8x8 region)
-//    items with a double-buffered LDS error tile filled by global_load_lds.  Work is split in chunks
-//    over the items; a small deterministic pass sums the per-chunk partials (no float atomics).
+//  * LANE = UNIT.  A wave owns AS input channels s and GP pairs of units g; its 64 lanes are two units x 32 output
+//    channels.  Every lane keeps its own four accumulators per (s, pair, image) for the whole kernel, so there is
+//    no cross-lane reduction (the reference needs cub::WarpReduce + atomics, :1747-1811).
+//  * The error tile sits in LDS position-major with the 32 output channels fastest ([row][col][f][image]), so lane f
+//    always hits bank pair f: conflict-free ds_read_b64 at ANY per-lane displacement.  Two images are interleaved
+//    element-wise, so every packed operand is a natural register pair (image n, image n+1).
+//  * Per (position, unit pair, image pair): 4 v_pk_*_f32 interpolate Et (bilinear factors broadcast with op_sel) and
+//    2 v_mfma_f32_4x4x1 contract it with the four kinds: the position q is wave-uniform; one 64-lane load fetches
+//    Xk of 16 positions (lane 4b+i = kind i of position b) and the MFMA of position b broadcasts block b's A operand
+//    to all blocks (CBSZ/ABID), D register k of a lane = its gradient kind k.
+//  * A workgroup owns (32 output channels, a block of input channels, a block of four units) and walks (image pair,
+//    8x8 region) items with the LDS error tile filled by global_load_lds (two tiles for bucket 4, one for bucket 8).
+//    Buckets 16/32 run as 4/16 offset-window passes of the bucket-8 tile (units outside the window are zeroed).
+//    Work is split in chunks over the items; a small deterministic pass sums the partials (no float atomics).
+//  Tuning knobs (timing experiments only): -DDAU_DOT_WAVES=8, DAU_DOT_NBUF=1, DAU_DOT_AS1, DAU_DOT_DEBUG.
 #include <cstdlib>
 #include <type_traits>
 
