@@ -527,25 +527,55 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                     // The group's GS positions x GP unit pairs: first ALL interpolation blocks (16 packed ops), then ALL
                     // kind-contractions (8 MFMAs).  Alternating the packed-VALU and MFMA pipes in small groups is slow on
                     // gfx950 (tools/microbench/mfma_pk_grouping: 2 MFMA + 4 pk per switch 125 TF, 8 + 16: 143 TF).
+                    // Et = b00*E[q-o] + b01*E[q-o-(0,1)] + b10*E[q-o-(1,0)] + b11*E[q-o-(1,1)] for the group's four
+                    // (position, unit pair) elements.  The four chains are interleaved instruction by instruction, so that
+                    // no packed op depends on the one issued just before it; within a chain every dependency is through the
+                    // accumulator operand, which needs no wait state.  (One asm block: the hazard recognizer would put an
+                    // s_nop between separate asm statements that feed each other.)
                     f2 et[GS][GP];
+                    f2 e0[GS][GP], l0[GS][GP], e1[GS][GP], l1[GS][GP];
 #pragma unroll
                     for (int p = 0; p < GS; ++p) {
 #pragma unroll
                         for (int gp = 0; gp < GP; ++gp) {
-                            const f2 e1 = eb[par][gp][0][p], e0 = eb[par][gp][1][p];
+                            e1[p][gp] = eb[par][gp][0][p]; e0[p][gp] = eb[par][gp][1][p];
                             // column to the left: this group's previous column, the row's column 0, or the previous group's last
-                            const f2 l1 = p > 0 ? eb[par][gp][0][p > 0 ? p - 1 : 0] : (gq == 0 ? epn[gp][0] : eb[par ^ 1][gp][0][GS - 1]);
-                            const f2 l0 = p > 0 ? eb[par][gp][1][p > 0 ? p - 1 : 0] : (gq == 0 ? epn[gp][1] : eb[par ^ 1][gp][1][GS - 1]);
-                            // Et = b00*E[q-o] + b01*E[q-o-(0,1)] + b10*E[q-o-(1,0)] + b11*E[q-o-(1,1)]; every dependency is
-                            // through the accumulator operand, which needs no wait state
-                            asm volatile("v_pk_mul_f32 %0, %1, %5 op_sel_hi:[1,0]\n\t"
-                                         "v_pk_fma_f32 %0, %2, %5, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                                         "v_pk_fma_f32 %0, %3, %6, %0 op_sel_hi:[1,0,1]\n\t"
-                                         "v_pk_fma_f32 %0, %4, %6, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
-                                         : "=&v"(et[p][gp])
-                                         : "v"(e0), "v"(l0), "v"(e1), "v"(l1), "v"(bw[si][gp][0]), "v"(bw[si][gp][1]));
+                            l1[p][gp] = p > 0 ? eb[par][gp][0][p > 0 ? p - 1 : 0] : (gq == 0 ? epn[gp][0] : eb[par ^ 1][gp][0][GS - 1]);
+                            l0[p][gp] = p > 0 ? eb[par][gp][1][p > 0 ? p - 1 : 0] : (gq == 0 ? epn[gp][1] : eb[par ^ 1][gp][1][GS - 1]);
                         }
                     }
+#define DAU_INTERP4(o0, o1, o2, o3, E0, L0, E1, L1, A0, A1, A2, A3, B0, B1, B2, B3)                                  \
+    asm volatile("v_pk_mul_f32 %0, %4, %20 op_sel_hi:[1,0]\n\t"                                                     \
+                 "v_pk_mul_f32 %1, %5, %21 op_sel_hi:[1,0]\n\t"                                                     \
+                 "v_pk_mul_f32 %2, %6, %22 op_sel_hi:[1,0]\n\t"                                                     \
+                 "v_pk_mul_f32 %3, %7, %23 op_sel_hi:[1,0]\n\t"                                                     \
+                 "v_pk_fma_f32 %0, %8, %20, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                                \
+                 "v_pk_fma_f32 %1, %9, %21, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                                \
+                 "v_pk_fma_f32 %2, %10, %22, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                               \
+                 "v_pk_fma_f32 %3, %11, %23, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                               \
+                 "v_pk_fma_f32 %0, %12, %24, %0 op_sel_hi:[1,0,1]\n\t"                                              \
+                 "v_pk_fma_f32 %1, %13, %25, %1 op_sel_hi:[1,0,1]\n\t"                                              \
+                 "v_pk_fma_f32 %2, %14, %26, %2 op_sel_hi:[1,0,1]\n\t"                                              \
+                 "v_pk_fma_f32 %3, %15, %27, %3 op_sel_hi:[1,0,1]\n\t"                                              \
+                 "v_pk_fma_f32 %0, %16, %24, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                               \
+                 "v_pk_fma_f32 %1, %17, %25, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                               \
+                 "v_pk_fma_f32 %2, %18, %26, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                               \
+                 "v_pk_fma_f32 %3, %19, %27, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]"                                    \
+                 : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)                                                         \
+                 : "v"(E0[0]), "v"(E0[1]), "v"(E0[2]), "v"(E0[3]), "v"(L0[0]), "v"(L0[1]), "v"(L0[2]), "v"(L0[3]),   \
+                   "v"(E1[0]), "v"(E1[1]), "v"(E1[2]), "v"(E1[3]), "v"(L1[0]), "v"(L1[1]), "v"(L1[2]), "v"(L1[3]),   \
+                   "v"(A0), "v"(A1), "v"(A2), "v"(A3), "v"(B0), "v"(B1), "v"(B2), "v"(B3))
+                    {
+                        // flatten [GS][GP] (GS*GP == 4 in every instantiation) into chain order
+                        static_assert(GS * GP == 4, "four interleaved chains");
+                        const f2* pe0 = &e0[0][0]; const f2* pl0 = &l0[0][0]; const f2* pe1 = &e1[0][0]; const f2* pl1 = &l1[0][0];
+                        f2* po = &et[0][0];
+                        // chain c = p * GP + gp uses the factors of unit pair gp = c % GP
+                        DAU_INTERP4(po[0], po[1], po[2], po[3], pe0, pl0, pe1, pl1,
+                                    bw[si][0 % GP][0], bw[si][1 % GP][0], bw[si][2 % GP][0], bw[si][3 % GP][0],
+                                    bw[si][0 % GP][1], bw[si][1 % GP][1], bw[si][2 % GP][1], bw[si][3 % GP][1]);
+                    }
+#undef DAU_INTERP4
                     __builtin_amdgcn_sched_barrier(0);
                     // the other buffer's last column (left neighbour of this group's first position) is now consumed
                     { DAU_PREFETCH_COL(GS - 1) }
