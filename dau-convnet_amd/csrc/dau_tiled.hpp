@@ -20,6 +20,7 @@ struct TiledConfig {
     int tiles_x, tiles_y;   // 8x8 position tiles of a patch
     int fblock;       // out-channels per workgroup
     int variant;      // kernel instantiation id
+    int debug;        // DAU_GATHER_DEBUG at plan creation (timing experiments)
 };
 
 bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, TiledConfig* cfg);
@@ -39,6 +40,8 @@ struct TiledDotConfig {
     int NP;
     int variant;
     int windows;      // offset-window passes: 1 for R <= 8, 4 for R = 16, 16 for R = 32
+    bool as1, one_tile;   // tuning choices read from the environment at plan creation
+    int debug;
 };
 
 bool tiled_dot_configure(const Shape& sh, int R, int blur_k, TiledDotConfig* cfg);

@@ -69,7 +69,8 @@ struct DotGeometry {
     size_t tile_bytes;          // padded to 1 KiB
 };
 
-DotGeometry make_dot_geometry(const Shape& sh, int R) {
+// as1 / one_tile: tuning choices fixed at plan creation (TiledDotConfig), so that every later call sees the same layout
+DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one_tile = false) {
     DotGeometry g{};
     g.Rt = R < 8 ? R : 8;
     g.nsub1 = R / g.Rt;
@@ -83,7 +84,7 @@ DotGeometry make_dot_geometry(const Shape& sh, int R) {
     g.Wp = g.rx * kRW;
     g.GP = sh.G <= 2 ? 1 : 2;
     g.ngb = (sh.G + 2 * g.GP - 1) / (2 * g.GP);
-    g.AS = (getenv("DAU_DOT_AS1") && g.GP == 2) ? 1 : 2;
+    g.AS = (as1 && g.GP == 2) ? 1 : 2;
     g.sblock = kDWaves * g.AS;
     g.nfb = (sh.F + kDF - 1) / kDF;
     g.nsb = (sh.S + g.sblock - 1) / g.sblock;
@@ -96,7 +97,7 @@ DotGeometry make_dot_geometry(const Shape& sh, int R) {
     g.chunks = chunks;
     g.tile_bytes = round_up((size_t)g.erows * g.epitch * kDF * 8, 1024);
     g.nbuf = 2 * g.tile_bytes <= 160 * 1024 ? 2 : 1;
-    if (getenv("DAU_DOT_NBUF") && atoi(getenv("DAU_DOT_NBUF")) == 1) g.nbuf = 1;   // timing experiments
+    if (one_tile) g.nbuf = 1;
     return g;
 }
 
@@ -662,18 +663,17 @@ void blur4_plan(int k, int Hp, int Wp, int* wy, int* wx, size_t* lds) {
 template <int GP, int AS>
 void launch_dot(hipStream_t st, const DotArgs& a, int grid, size_t lds) {
     auto kern = gather_dot_kernel<GP, AS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kDWaves * 64), lds, st, a);
 }
 
 }  // namespace
 
 bool tiled_dot_configure(const Shape& sh, int R, int blur_k, TiledDotConfig* cfg) {
-    const DotGeometry g = make_dot_geometry(sh, R);
+    // timing experiments: DAU_DOT_AS1 (one input channel per wave), DAU_DOT_NBUF=1 (one error tile), DAU_DOT_DEBUG
+    const bool as1 = getenv("DAU_DOT_AS1") != nullptr;
+    const bool one_tile = getenv("DAU_DOT_NBUF") && atoi(getenv("DAU_DOT_NBUF")) == 1;
+    const DotGeometry g = make_dot_geometry(sh, R, as1, one_tile);
     if (g.tile_bytes > 160 * 1024) return false;
     if ((size_t)64 * (sh.W | 1) * 4 > 160 * 1024) return false;   // pack_error_kernel transposes whole rows through LDS
     // immediates of the unrolled column walk must fit 16 bits
@@ -685,28 +685,25 @@ bool tiled_dot_configure(const Shape& sh, int R, int blur_k, TiledDotConfig* cfg
     }
     TiledDotConfig c{};
     c.sh = sh; c.R = R; c.blur_k = blur_k; c.NP = (sh.N + 1) / 2; c.variant = g.GP; c.windows = g.nsub1 * g.nsub1;
+    c.as1 = as1; c.one_tile = one_tile; c.debug = getenv("DAU_DOT_DEBUG") ? atoi(getenv("DAU_DOT_DEBUG")) : 0;
     *cfg = c;
     return true;
 }
 
 size_t tiled_dot_workspace_bytes(const TiledDotConfig& c) {
-    return dot_layout(c, make_dot_geometry(c.sh, c.R)).total;
+    return dot_layout(c, make_dot_geometry(c.sh, c.R, c.as1, c.one_tile)).total;
 }
 
 void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, const float* dy, const float* filters,
                        const UnitRef* table_bare, int drop_col, int drop_row, void* workspace) {
-    const DotGeometry g = make_dot_geometry(c.sh, c.R);
+    const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile);
     const DotLayout l = dot_layout(c, g);
     char* ws = static_cast<char*>(workspace);
     const Shape& s = c.sh;
     const int s_pad = g.nsb * g.sblock;
     {
         const size_t lds = (size_t)64 * (s.W | 1) * 4;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pack_error_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pack_error_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(pack_error_kernel, dim3(c.NP * g.nfb * g.EY), dim3(256), lds, st, dy, s.N, s.F, s.H, s.W, c.R, g.EX,
                            g.EY, g.nfb, drop_col, drop_row, reinterpret_cast<float*>(ws + l.ep_off));
     }
@@ -732,7 +729,7 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
 }
 
 void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* workspace) {
-    const DotGeometry g = make_dot_geometry(c.sh, c.R);
+    const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile);
     const DotLayout l = dot_layout(c, g);
     char* ws = static_cast<char*>(workspace);
     const Shape& s = c.sh;
@@ -746,7 +743,7 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
     a.rx = g.rx; a.ry = g.ry; a.EX = g.EX; a.EY = g.EY; a.Hp = g.Hp; a.Wp = g.Wp; a.epitch = g.epitch; a.erows = g.erows;
     a.s_pad = g.nsb * g.sblock;
     a.tile_bytes = (unsigned)g.tile_bytes;
-    a.debug = getenv("DAU_DOT_DEBUG") ? atoi(getenv("DAU_DOT_DEBUG")) : 0;
+    a.debug = c.debug;
     const int grid = g.chunks * g.nsub1 * g.nsub1 * g.nfb * g.ngb * g.nsb;
     const size_t lds = (size_t)g.nbuf * g.tile_bytes;
     switch (g.GP) {

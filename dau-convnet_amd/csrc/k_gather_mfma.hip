@@ -97,10 +97,16 @@ Geometry make_geometry(int H, int W, int R, int G, int N, int Cout, int only = -
     g.H = H; g.W = W; g.R = R; g.variant = -1;
     g.Rt = R > 16 ? 16 : R; g.nwin1 = R / g.Rt;
     R = g.Rt;                                                // everything below sizes ONE plane
-    const char* split_env = getenv("DAU_GATHER_SPLIT");      // tuning knob: waves per output channel
-    const int want_split = split_env ? atoi(split_env) : 0;
-    // DAU_GATHER_VARIANT=<row> at plan creation pins the kernel (tests of the small-map variants on small batches)
-    if (only < 0 && getenv("DAU_GATHER_VARIANT")) only = atoi(getenv("DAU_GATHER_VARIANT"));
+    // The environment is consulted at plan creation only (only < 0); afterwards the plan's row is passed in.
+    //   DAU_GATHER_VARIANT=<row>  pins the kernel (tests of the small-map variants on small batches)
+    //   DAU_GATHER_SPLIT=3        the three-waves-per-channel tuning alternative;  DAU_GATHER_STACK=0  never stack
+    int want_split = 0;
+    bool never_stack = false;
+    if (only < 0) {
+        if (getenv("DAU_GATHER_SPLIT")) want_split = atoi(getenv("DAU_GATHER_SPLIT"));
+        never_stack = getenv("DAU_GATHER_STACK") && atoi(getenv("DAU_GATHER_STACK")) == 0;
+        if (getenv("DAU_GATHER_VARIANT")) only = atoi(getenv("DAU_GATHER_VARIANT"));
+    }
     double best = 0.0;
     for (int i = 0; i < (int)(sizeof(kVariants) / sizeof(kVariants[0])); ++i) {
         const Variant& v = kVariants[i];
@@ -123,8 +129,7 @@ Geometry make_geometry(int H, int W, int R, int G, int N, int Cout, int only = -
         if (2 * v.sk * plane + 2 * ut_stride_bytes(G, v.fb) > 160 * 1024) continue;
         const int npx = (W + pw - 1) / pw, npy = (H + ph - 1) / ph;
         const long planes = (long)((N + 1) / 2) * npx * npy, groups = (planes + v.sk - 1) / v.sk;
-        // (DAU_GATHER_STACK=0 at plan creation: never stack, for A/B timing)
-        if (only < 0 && v.sk > 1 && getenv("DAU_GATHER_STACK") && atoi(getenv("DAU_GATHER_STACK")) == 0) continue;
+        if (never_stack && v.sk > 1) continue;
         const long blocks = groups * ((Cout + v.fb - 1) / v.fb);
         // relative cost in tile units: MFMA tiles + the DMA of the planes + a fixed part per workgroup and channel
         // (barrier, unit fetch, exposed LDS latency: ~12 tiles' worth, fitted to 28x28 stacked vs plain)
@@ -591,11 +596,7 @@ namespace {
 template <class T>
 void launch_variant(hipStream_t st, const GatherArgs& a, int grid, size_t lds) {
     auto kern = gather_mfma_kernel<T>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T::kThreads), lds, st, a);
 }
 
@@ -622,6 +623,7 @@ bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R
     c.NP = (N + 1) / 2;
     c.rows = g.rows; c.pitch = g.pitch; c.tiles_x = g.tx; c.tiles_y = g.ty; c.fblock = g.fb; c.variant = g.variant;
     c.patches = g.npx * g.npy; c.stack = g.sk; c.windows = g.nwin1 * g.nwin1;
+    c.debug = getenv("DAU_GATHER_DEBUG") ? atoi(getenv("DAU_GATHER_DEBUG")) : 0;
     if (lds_bytes(c, g) > 160 * 1024) return false;
     // blur_pack keeps both raw planes (+ blur halo) and the horizontally filtered rows in LDS
     if (blur_pack_lds_bytes(g, blur_k) > 150 * 1024) return false;
@@ -682,7 +684,7 @@ void tiled_gather_run(hipStream_t st, const TiledConfig& c, float* out, void* wo
     a.strip_off = (unsigned)g.strip_off;
     a.ut_stride = (unsigned)ut_stride_bytes(c.G, g.fb);
     a.zpitch = (unsigned)(g.pw + 2);
-    a.debug = getenv("DAU_GATHER_DEBUG") ? atoi(getenv("DAU_GATHER_DEBUG")) : 0;
+    a.debug = c.debug;
     const int grid = ((c.NP * c.patches + g.sk - 1) / g.sk) * a.nfb;
     const size_t lds = lds_bytes(c, g);
     switch (c.variant) {
