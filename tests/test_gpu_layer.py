@@ -127,3 +127,17 @@ def test_layer_raises_like_the_reference_ops():
         dau_conv.dau_conv(x, w, far, mu, sigma, num_output=4, kernel_size=65)
     with pytest.raises(dau_conv.InvalidArgumentError):         # shape function: last dim == num_output
         dau_conv.dau_conv(x, w, mu, mu, sigma, num_output=8, kernel_size=9)
+
+
+def test_toy_training_loop_reduces_the_loss():
+    """examples/train_toy.py: two stacked DAUConv2d layers fitted with Adam to a teacher DAU layer; weights, offsets and
+    biases all move through the operator's gradients, so the loss has to fall."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "train_toy", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "train_toy.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    losses = mod.run(steps=60, verbose=False)
+    assert all(l == l for l in losses)                      # no NaN
+    assert sum(losses[-5:]) / 5 < 0.6 * sum(losses[:5]) / 5, (losses[:5], losses[-5:])
