@@ -169,7 +169,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import dau_oracle as orc
-        ncpu = min(N, 16)
+        ncpu = min(N, 32)
         xs, dys = x[:ncpu].cpu().numpy(), dy[:ncpu].cpu().numpy()
         wn, m1, m2 = w.cpu().numpy(), mu1.cpu().numpy(), mu2.cpu().numpy()
         orc.forward(xs[:1, :4], wn[:, :4], m1[:, :4], m2[:, :4], 0.5)   # load + warm the library
