@@ -57,15 +57,18 @@ struct DotGeometry {
     int rx, ry;                 // regions per image
     int EX, EY;                 // staged error plane (positions): regions*8 + 2R + 1
     int Hp, Wp;                 // staged Xk plane (positions): regions*8
-    int GP;                     // unit pairs per (s,f) handled by one wave (1 or 2)
-    int ngb;                    // unit blocks of 2*GP units: G > 4 is covered by several workgroups per (s-block, f-block)
+    // The units of a channel are covered by up to two kernel passes: blocks of four units (two unit pairs per wave, two
+    // input channels per wave) and, for a remainder of one or two units, one unit pair per wave with four input channels
+    // per wave -- every wave carries four (channel, pair) slots either way.  A remainder of three takes a four-unit block.
+    struct Pass { int g_begin, GP, AS, ngb, sblock, nsb, chunks; size_t params_off, params_bytes; };
+    int npass;
+    Pass pass[2];
     int nbuf;                   // error tiles resident in LDS: 2 (load under compute) or 1 (R = 8: one tile fills the LDS)
     int Rt;                     // offset radius one LDS tile covers: min(R, 8)
     int nsub1;                  // R > 8: the offset range is cut into nsub1 x nsub1 windows of radius Rt; one workgroup
                                 // pass per window, units outside the window contribute zero (their factors are zeroed)
-    int AS;                     // input channels per wave
-    int sblock;                 // input channels per workgroup
-    int nfb, nsb, chunks, items;
+    int s_pad;                  // input channels padded to whole workgroups of every pass
+    int nfb, chunks, items;
     size_t tile_bytes;          // padded to 1 KiB
 };
 
@@ -82,19 +85,39 @@ DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one
     g.EY = g.ry * kRH + 2 * R + 1;
     g.Hp = g.ry * kRH;
     g.Wp = g.rx * kRW;
-    g.GP = sh.G <= 2 ? 1 : 2;
-    g.ngb = (sh.G + 2 * g.GP - 1) / (2 * g.GP);
-    g.AS = (as1 && g.GP == 2) ? 1 : 2;
-    g.sblock = kDWaves * g.AS;
     g.nfb = (sh.F + kDF - 1) / kDF;
-    g.nsb = (sh.S + g.sblock - 1) / g.sblock;
+    {
+        const int full4 = sh.G / 4, rem = sh.G % 4;
+        const int blocks4 = full4 + (rem == 3 ? 1 : 0);
+        g.npass = 0;
+        if (blocks4 > 0) g.pass[g.npass++] = DotGeometry::Pass{0, 2, as1 ? 1 : 2, blocks4, 0, 0, 0, 0, 0};
+        if (rem == 1 || rem == 2) g.pass[g.npass++] = DotGeometry::Pass{4 * full4, 1, 4, 1, 0, 0, 0, 0, 0};
+        g.s_pad = 0;
+        for (int i = 0; i < g.npass; ++i) {
+            DotGeometry::Pass& ps = g.pass[i];
+            ps.sblock = kDWaves * ps.AS;
+            ps.nsb = (sh.S + ps.sblock - 1) / ps.sblock;
+            if (ps.nsb * ps.sblock > g.s_pad) g.s_pad = ps.nsb * ps.sblock;
+        }
+        size_t off = 0;
+        for (int i = 0; i < g.npass; ++i) {
+            DotGeometry::Pass& ps = g.pass[i];
+            ps.params_off = off;
+            ps.params_bytes = round_up((size_t)g.nsub1 * g.nsub1 * g.s_pad * ps.ngb * ps.GP * g.nfb * 64 * kParamDwords * 4, 256);
+            off += ps.params_bytes;
+        }
+    }
     g.items = ((sh.N + 1) / 2) * g.rx * g.ry;
-    // enough workgroups to fill the chip several times over, but no more chunks than items
-    const int per_chunk = g.nfb * g.nsb * g.ngb * g.nsub1 * g.nsub1;
-    int chunks = (256 * 4 + per_chunk - 1) / per_chunk;
-    if (chunks > g.items) chunks = g.items;
-    if (chunks < 1) chunks = 1;
-    g.chunks = chunks;
+    // per pass: enough workgroups to fill the chip several times over, but no more chunks than items
+    g.chunks = 1;
+    for (int i = 0; i < g.npass; ++i) {
+        const int per_chunk = g.nfb * g.pass[i].nsb * g.pass[i].ngb * g.nsub1 * g.nsub1;
+        int chunks = (256 * 4 + per_chunk - 1) / per_chunk;
+        if (chunks > g.items) chunks = g.items;
+        if (chunks < 1) chunks = 1;
+        g.pass[i].chunks = chunks;
+        if (chunks > g.chunks) g.chunks = chunks;           // slabs allocated for the partial sums
+    }
     g.tile_bytes = round_up((size_t)g.erows * g.epitch * kDF * 8, 1024);
     g.nbuf = 2 * g.tile_bytes <= 160 * 1024 ? 2 : 1;
     if (one_tile) g.nbuf = 1;
@@ -232,9 +255,9 @@ __global__ void __launch_bounds__(512) blur4_pack_kernel(const Blur4Args a) {
 }
 
 // per-lane parameters: params[sub][s][gb][gp][fb][lane][8] = {b00, b01, b10, b11, base, 0, 0, 0}
-// lane = half*32 + fl ; unit = (s, g = gb*2*GP + 2*gp + half, f = fb*32 + fl); invalid units get zero factors.
+// lane = half*32 + fl ; unit = (s, g = g_begin + gb*2*GP + 2*gp + half, f = fb*32 + fl); invalid units get zero factors.
 __global__ void dot_params_kernel(const UnitRef* __restrict__ table, int S, int G, int F, int R, int Rt, int nsub1,
-                                  int epitch, int GP, int ngb, int nfb, int s_pad, float* __restrict__ params) {
+                                  int epitch, int g_begin, int GP, int ngb, int nfb, int s_pad, float* __restrict__ params) {
     const long total = (long)nsub1 * nsub1 * s_pad * ngb * GP * nfb * 64;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(idx % 64);
@@ -244,7 +267,7 @@ __global__ void dot_params_kernel(const UnitRef* __restrict__ table, int S, int 
         const int gb = (int)(t % ngb); t /= ngb;
         const int s = (int)(t % s_pad);
         const int sub = (int)(t / s_pad);
-        const int g = gb * 2 * GP + 2 * gp + (lane >> 5), fl = lane & 31, f = fb * kDF + fl;
+        const int g = g_begin + gb * 2 * GP + 2 * gp + (lane >> 5), fl = lane & 31, f = fb * kDF + fl;
         UnitRef u{0, 0, 0.0f, 0.0f, 0.0f, 0.0f};
         if (s < S && g < G && f < F) u = table[((long)s * G + g) * F + f];
         // offset window of this pass: centre c = -R + Rt + 2*Rt*i per axis; a unit belongs to exactly one window
@@ -259,11 +282,15 @@ __global__ void dot_params_kernel(const UnitRef* __restrict__ table, int S, int 
     }
 }
 
-// r4[k][u] = sum over chunks of partial[chunk][k][u]
-__global__ void dot_reduce_kernel(const float* __restrict__ partial, long n, int chunks, float* __restrict__ r4) {
+// r4[k][u] = sum over the slabs of partial[slab][k][u]; units g < g_split were written by a pass with slabs0 slabs,
+// the others by a pass with slabs1 (u = (s*G + g)*F + f)
+__global__ void dot_reduce_kernel(const float* __restrict__ partial, long n, int G, int F, int g_split, int slabs0,
+                                  int slabs1, float* __restrict__ r4) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int g = (int)((i / F) % G);
+        const int slabs = g < g_split ? slabs0 : slabs1;
         double s = 0.0;
-        for (int c = 0; c < chunks; ++c) s += (double)partial[(long)c * n + i];
+        for (int c = 0; c < slabs; ++c) s += (double)partial[(long)c * n + i];
         r4[i] = (float)s;
     }
 }
@@ -277,6 +304,7 @@ struct DotArgs {
     const float* params;
     float* partial;
     int N, S, F, G, R;
+    int g_begin;                // first unit of this pass
     int NP, nfb, nsb, ngb, nbuf, chunks, items;
     int Rt, nsub1;
     int rx, ry, EX, EY, Hp, Wp, epitch, erows, s_pad;
@@ -618,7 +646,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     for (int si = 0; si < AS; ++si)
 #pragma unroll
         for (int gp = 0; gp < GP; ++gp) {
-            const int s = s_of[si], g = gb * 2 * GP + 2 * gp + half;
+            const int s = s_of[si], g = a.g_begin + gb * 2 * GP + 2 * gp + half;
             if (s < a.S && g < a.G && f < a.F) {
                 float* dst = a.partial + ((long)chunk * nsub + sub) * kNumK * units + ((long)s * a.G + g) * a.F + f;
 #pragma unroll
@@ -639,12 +667,13 @@ struct DotLayout {
 DotLayout dot_layout(const TiledDotConfig& c, const DotGeometry& g) {
     DotLayout l{};
     const size_t NP = (c.sh.N + 1) / 2;
-    const size_t s_pad = (size_t)g.nsb * g.sblock;
+    const size_t s_pad = (size_t)g.s_pad;
     size_t off = 0;
     l.ep_off = off; off += round_up(NP * g.nfb * g.EY * g.EX * kDF * 8, 256);
     l.xk_off = off; off += round_up(NP * s_pad * g.Hp * g.Wp * 32, 256);
     const size_t nsub = (size_t)g.nsub1 * g.nsub1;
-    l.params_off = off; off += round_up(nsub * s_pad * g.ngb * g.GP * g.nfb * 64 * kParamDwords * 4, 256);
+    l.params_off = off;
+    for (int i = 0; i < g.npass; ++i) off += g.pass[i].params_bytes;
     l.partial_off = off; off += round_up(nsub * g.chunks * kNumK * c.sh.S * c.sh.G * c.sh.F * 4, 256);
     l.total = off;
     return l;
@@ -684,7 +713,7 @@ bool tiled_dot_configure(const Shape& sh, int R, int blur_k, TiledDotConfig* cfg
         if (blur_lds > 150 * 1024) return false;
     }
     TiledDotConfig c{};
-    c.sh = sh; c.R = R; c.blur_k = blur_k; c.NP = (sh.N + 1) / 2; c.variant = g.GP; c.windows = g.nsub1 * g.nsub1;
+    c.sh = sh; c.R = R; c.blur_k = blur_k; c.NP = (sh.N + 1) / 2; c.variant = g.npass; c.windows = g.nsub1 * g.nsub1;
     c.as1 = as1; c.one_tile = one_tile; c.debug = getenv("DAU_DOT_DEBUG") ? atoi(getenv("DAU_DOT_DEBUG")) : 0;
     *cfg = c;
     return true;
@@ -700,7 +729,7 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
     const DotLayout l = dot_layout(c, g);
     char* ws = static_cast<char*>(workspace);
     const Shape& s = c.sh;
-    const int s_pad = g.nsb * g.sblock;
+    const int s_pad = g.s_pad;
     {
         const size_t lds = (size_t)64 * (s.W | 1) * 4;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pack_error_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -720,11 +749,13 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
         b.WY = wy; b.WX = wx; b.nwy = (g.Hp + wy - 1) / wy; b.nwx = (g.Wp + wx - 1) / wx;
         hipLaunchKernelGGL(kern, dim3(c.NP * b.nwy * b.nwx * s.S), dim3(512), blur_lds, st, b);
     }
-    {
-        const long total = (long)g.nsub1 * g.nsub1 * s_pad * g.ngb * g.GP * g.nfb * 64;
+    for (int i = 0; i < g.npass; ++i) {
+        const DotGeometry::Pass& ps = g.pass[i];
+        const long total = (long)g.nsub1 * g.nsub1 * s_pad * ps.ngb * ps.GP * g.nfb * 64;
         const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         hipLaunchKernelGGL(dot_params_kernel, dim3(grid), dim3(256), 0, st, table_bare, s.S, s.G, s.F, c.R, g.Rt, g.nsub1,
-                           g.epitch, g.GP, g.ngb, g.nfb, s_pad, reinterpret_cast<float*>(ws + l.params_off));
+                           g.epitch, ps.g_begin, ps.GP, ps.ngb, g.nfb, s_pad,
+                           reinterpret_cast<float*>(ws + l.params_off + ps.params_off));
     }
 }
 
@@ -736,24 +767,29 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
     DotArgs a{};
     a.ep = ws + l.ep_off;
     a.xk = reinterpret_cast<const float*>(ws + l.xk_off);
-    a.params = reinterpret_cast<const float*>(ws + l.params_off);
     a.partial = reinterpret_cast<float*>(ws + l.partial_off);
     a.N = s.N; a.S = s.S; a.F = s.F; a.G = s.G; a.R = c.R;
-    a.NP = c.NP; a.nfb = g.nfb; a.nsb = g.nsb; a.ngb = g.ngb; a.nbuf = g.nbuf; a.Rt = g.Rt; a.nsub1 = g.nsub1; a.chunks = g.chunks; a.items = g.items;
+    a.NP = c.NP; a.nfb = g.nfb; a.nbuf = g.nbuf; a.Rt = g.Rt; a.nsub1 = g.nsub1; a.chunks = g.chunks; a.items = g.items;
     a.rx = g.rx; a.ry = g.ry; a.EX = g.EX; a.EY = g.EY; a.Hp = g.Hp; a.Wp = g.Wp; a.epitch = g.epitch; a.erows = g.erows;
-    a.s_pad = g.nsb * g.sblock;
+    a.s_pad = g.s_pad;
     a.tile_bytes = (unsigned)g.tile_bytes;
     a.debug = c.debug;
-    const int grid = g.chunks * g.nsub1 * g.nsub1 * g.nfb * g.ngb * g.nsb;
     const size_t lds = (size_t)g.nbuf * g.tile_bytes;
-    switch (g.GP) {
-        case 1: launch_dot<1, 2>(st, a, grid, lds); break;
-        case 2: if (g.AS == 2) launch_dot<2, 2>(st, a, grid, lds); else launch_dot<2, 1>(st, a, grid, lds); break;
-        default: break;
+    for (int i = 0; i < g.npass; ++i) {           // every pass writes its own units' slabs of the partial sums
+        const DotGeometry::Pass& ps = g.pass[i];
+        a.params = reinterpret_cast<const float*>(ws + l.params_off + ps.params_off);
+        a.g_begin = ps.g_begin; a.nsb = ps.nsb; a.ngb = ps.ngb; a.chunks = ps.chunks;
+        const int grid = ps.chunks * g.nsub1 * g.nsub1 * g.nfb * ps.ngb * ps.nsb;
+        if (ps.GP == 1) launch_dot<1, 4>(st, a, grid, lds);
+        else if (ps.AS == 2) launch_dot<2, 2>(st, a, grid, lds);
+        else launch_dot<2, 1>(st, a, grid, lds);
     }
     const long n = (long)kNumK * s.S * s.G * s.F;
     const int rgrid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(dot_reduce_kernel, dim3(rgrid), dim3(256), 0, st, a.partial, n, g.chunks * g.nsub1 * g.nsub1, r4);
+    const int nsub = g.nsub1 * g.nsub1;
+    const int g_split = g.npass == 2 ? g.pass[1].g_begin : s.G;
+    hipLaunchKernelGGL(dot_reduce_kernel, dim3(rgrid), dim3(256), 0, st, a.partial, n, s.G, s.F, g_split,
+                       g.pass[0].chunks * nsub, g.pass[g.npass - 1].chunks * nsub, r4);
 }
 
 }  // namespace dau

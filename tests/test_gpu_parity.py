@@ -181,6 +181,11 @@ def test_error_convention():
     # offset windows of the gather-dot for kernels 33 and 65 with offsets over the whole range
     dict(N=2, W=40, H=40, S=5, F=33, G=3, k=33, m=16),
     dict(N=1, W=48, H=40, S=3, F=8, G=2, k=65, m=32),
+    # gather-dot passes: 5 = 4 + 1, 7 = 4 + 3 (two four-unit blocks), 9 = 8 + 1, 10 = 8 + 2 units; odd channel counts
+    dict(N=2, W=16, H=24, S=35, F=33, G=5, k=9, m=3),
+    dict(N=2, W=16, H=16, S=9, F=40, G=7, k=9, m=3),
+    dict(N=1, W=24, H=16, S=66, F=20, G=9, k=9, m=3),
+    dict(N=3, W=16, H=16, S=5, F=32, G=10, k=17, m=7),
     # unit counts of the reference's dau_units (1x1 .. 4x2): one, odd, six and eight units per channel
     dict(N=2, W=16, H=16, S=5, F=40, G=1, k=9, m=3),
     dict(N=2, W=24, H=24, S=6, F=32, G=3, k=9, m=3),
