@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS))
     ap.add_argument("--shape", default=None, help="ad-hoc workload N,S,F,H,W,G,k[,m] (overrides --workload)")
+    ap.add_argument("--io", default="f32", choices=["f32", "bf16"],
+                    help="storage type of x, y, dy, dx (BASELINE config 2 names bf16); arithmetic is fp32 either way")
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 direct, 2 tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -100,7 +102,10 @@ def main():
     mu2 = ((torch.rand((1, S, G, F), device=dev, generator=pgen) * 2 - 1) * m).clamp_(-lim, lim)
     sigma = torch.full((1, S, G, F), 0.5, device=dev)
 
-    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, flags=_capi.FLAG_USE_INTERPOLATION, algo=args.algo,
+    if args.io == "bf16":
+        x, dy = x.to(torch.bfloat16), dy.to(torch.bfloat16)
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, algo=args.algo,
+                      flags=_capi.FLAG_USE_INTERPOLATION | (_capi.FLAG_IO_BF16 if args.io == "bf16" else 0),
                       sigma_hint=0.5, mu_learning_rate_factor=1.0)
     from dau_conv.distributed import OverlappedBackward
     exchange = OverlappedBackward((1, S, G, F), dev) if use_dist else None
@@ -184,7 +189,8 @@ def main():
         out = dict(metric="DAU fwd+bwd GSamples/s (N*H*W/s)", value=round(value, 6), unit="GSamples/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload=wl["label"], global_batch=N * world, parallelism="dp%d" % world,
+                   config=dict(workload=wl["label"] + (" [bf16 activations in HBM]" if args.io == "bf16" else ""),
+                               global_batch=N * world, parallelism="dp%d" % world,
                                algo_forward=plan.info["algo_forward"], algo_backward=plan.info["algo_backward"]),
                    roofline=roofline, cpu_baseline=cpu)
         print(json.dumps(out))

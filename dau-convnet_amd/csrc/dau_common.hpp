@@ -7,6 +7,21 @@
 
 namespace dau {
 
+// bfloat16 I/O (DAU_FLAG_IO_BF16): activations are stored as the upper 16 bits of an fp32
+__device__ __forceinline__ float load_act(const float* base, long idx, bool bf16) {
+    if (!bf16) return base[idx];
+    return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(base)[idx] << 16);
+}
+__device__ __forceinline__ void store_act(float* base, long idx, float v, bool bf16, bool accumulate) {
+    if (!bf16) { base[idx] = accumulate ? base[idx] + v : v; return; }
+    unsigned short* p = reinterpret_cast<unsigned short*>(base) + idx;
+    if (accumulate) v += __uint_as_float((unsigned)*p << 16);
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);               // round to nearest even (NaN stays NaN: the payload only grows)
+    *p = (unsigned short)(u >> 16);
+}
+
+
 constexpr int kMaxBlurSupport = 17;                       // convolve.cu:40 caps the prefilter at 17x17
 constexpr int kFilterPlane = kMaxBlurSupport * kMaxBlurSupport;
 constexpr int kNumK = 4;                                  // gradient kinds {w, mu1, mu2, sigma}

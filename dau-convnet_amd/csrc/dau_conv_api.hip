@@ -215,9 +215,14 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
     p->drop_row = ut ? edge_disabled(desc->height) : 0;
 
     const Shape& s = p->sh;
-    const bool fwd_ok = tiled_gather_configure(s.N, s.S, s.F, s.G, s.H, s.W, bucket, blur_k, &p->tiled_fwd) &&
-                        tiled_gather_configure(s.N, s.F, s.S, s.G, s.H, s.W, bucket, blur_k, &p->tiled_dx);
-    const bool dot_ok = tiled_dot_configure(s, bucket, blur_k, &p->tiled_dot);
+    const bool bf16 = (desc->flags & DAU_FLAG_IO_BF16) != 0;
+    const bool fwd_ok = tiled_gather_configure(s.N, s.S, s.F, s.G, s.H, s.W, bucket, blur_k, bf16, &p->tiled_fwd) &&
+                        tiled_gather_configure(s.N, s.F, s.S, s.G, s.H, s.W, bucket, blur_k, bf16, &p->tiled_dx);
+    const bool dot_ok = tiled_dot_configure(s, bucket, blur_k, bf16, &p->tiled_dot);
+    if (bf16 && (desc->algo == DAU_ALGO_DIRECT || !(fwd_ok && dot_ok))) {
+        delete p;
+        return fail(DAU_INVALID_ARGUMENT, "DAU_FLAG_IO_BF16 needs the tiled kernels, which do not support this shape / algo");
+    }
     if (desc->algo == DAU_ALGO_TILED && !(fwd_ok && dot_ok)) {
         delete p;
         return fail(DAU_INVALID_ARGUMENT, "DAU_ALGO_TILED does not support this shape");

@@ -21,9 +21,10 @@ struct TiledConfig {
     int fblock;       // out-channels per workgroup
     int variant;      // kernel instantiation id
     int debug;        // DAU_GATHER_DEBUG at plan creation (timing experiments)
+    int bf16;         // activations in and out are bfloat16
 };
 
-bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, TiledConfig* cfg);
+bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, bool bf16, TiledConfig* cfg);
 size_t tiled_gather_workspace_bytes(const TiledConfig& cfg);
 // prepare: blur `in` ([N,Cin,H,W]) with the Gaussian (`filters` = output of launch_synth_filters; `mirrored`
 // selects the flipped kernel of the input-gradient pass) into the staged pair-interleaved planes and pack the
@@ -41,10 +42,11 @@ struct TiledDotConfig {
     int variant;
     int windows;      // offset-window passes: 1 for R <= 8, 4 for R = 16, 16 for R = 32
     bool as1, one_tile;   // tuning choices read from the environment at plan creation
+    bool bf16;            // x and dy are bfloat16
     int debug;
 };
 
-bool tiled_dot_configure(const Shape& sh, int R, int blur_k, TiledDotConfig* cfg);
+bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, TiledDotConfig* cfg);
 size_t tiled_dot_workspace_bytes(const TiledDotConfig& cfg);
 // r4[k][s][g][f] = sum_{n,p} dy'[n,f,p] * bilinear(x * D_k, p + o);  `filters` = output of launch_synth_filters.
 void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& cfg, const float* x, const float* dy,

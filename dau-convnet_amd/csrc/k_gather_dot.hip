@@ -134,7 +134,7 @@ DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one
 // One workgroup per (pair, channel block, padded row): 64 coalesced row reads -> LDS -> one contiguous
 // EX*256 B write (a transpose from channel-major to position-major).  HBM bound.
 __global__ void __launch_bounds__(256) pack_error_kernel(const float* __restrict__ dy, int N, int F, int H, int W, int R,
-                                                         int EX, int EY, int nfb, int drop_col, int drop_row,
+                                                         int EX, int EY, int nfb, int drop_col, int drop_row, int bf16,
                                                          float* __restrict__ ep) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [64 = 32 f x 2 images][W | 1]
     const int Y = blockIdx.x % EY;
@@ -148,8 +148,8 @@ __global__ void __launch_bounds__(256) pack_error_kernel(const float* __restrict
         for (int r = wave; r < 64; r += nw) {               // r = fl*2 + image
             const int f = fb * kDF + (r >> 1), n = 2 * np + (r & 1);
             const bool ok = f < F && n < N;
-            const float* src = dy + (((long)(ok ? n : 0) * F + (ok ? f : 0)) * H + y) * W;
-            for (int x = lane; x < W; x += 64) lds[r * wp + x] = ok ? src[x] : 0.0f;
+            const long src = (((long)(ok ? n : 0) * F + (ok ? f : 0)) * H + y) * W;
+            for (int x = lane; x < W; x += 64) lds[r * wp + x] = ok ? load_act(dy, src + x, bf16 != 0) : 0.0f;
         }
     }
     __syncthreads();
@@ -169,6 +169,7 @@ struct Blur4Args {
     const float* taps;
     float* xk;
     int N, C, cstride, H, W, k, Hp, Wp;
+    int bf16;                   // input is bfloat16
     int WY, WX, nwy, nwx;       // output window (rows x columns of the Hp x Wp plane) and windows per plane
 };
 
@@ -200,8 +201,8 @@ __global__ void __launch_bounds__(512) blur4_pack_kernel(const Blur4Args a) {
     auto tap = [&](int q, int i) { return K ? tr[q][i] : tp[q][i]; };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int n0 = 2 * np, n1 = 2 * np + 1;
-    const float* p0 = a.in + ((long)n0 * C + c) * H * W;
-    const float* p1 = a.in + ((long)(n1 < a.N ? n1 : n0) * C + c) * H * W;
+    const long p0 = ((long)n0 * C + c) * H * W, p1 = ((long)(n1 < a.N ? n1 : n0) * C + c) * H * W;   // element offsets
+    const bool bf16 = a.bf16 != 0;
     const float m1 = n1 < a.N ? 1.0f : 0.0f;
     for (int r = wave; r < lh; r += nw) {
         const int yy = oy0 - kr + r;
@@ -209,7 +210,7 @@ __global__ void __launch_bounds__(512) blur4_pack_kernel(const Blur4Args a) {
         for (int xl = lane; xl < lw; xl += 64) {
             const int xx = ox0 - kr + xl;
             f2 v = {0.0f, 0.0f};
-            if (rowin && xx >= 0 && xx < W) { v.x = p0[yy * W + xx]; v.y = m1 * p1[yy * W + xx]; }
+            if (rowin && xx >= 0 && xx < W) { v.x = load_act(a.in, p0 + yy * W + xx, bf16); v.y = m1 * load_act(a.in, p1 + yy * W + xx, bf16); }
             A[r * lw + xl] = v;
         }
     }
@@ -698,7 +699,7 @@ void launch_dot(hipStream_t st, const DotArgs& a, int grid, size_t lds) {
 
 }  // namespace
 
-bool tiled_dot_configure(const Shape& sh, int R, int blur_k, TiledDotConfig* cfg) {
+bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, TiledDotConfig* cfg) {
     // timing experiments: DAU_DOT_AS1 (one input channel per wave), DAU_DOT_NBUF=1 (one error tile), DAU_DOT_DEBUG
     const bool as1 = getenv("DAU_DOT_AS1") != nullptr;
     const bool one_tile = getenv("DAU_DOT_NBUF") && atoi(getenv("DAU_DOT_NBUF")) == 1;
@@ -714,6 +715,7 @@ bool tiled_dot_configure(const Shape& sh, int R, int blur_k, TiledDotConfig* cfg
     }
     TiledDotConfig c{};
     c.sh = sh; c.R = R; c.blur_k = blur_k; c.NP = (sh.N + 1) / 2; c.variant = g.npass; c.windows = g.nsub1 * g.nsub1;
+    c.bf16 = bf16;
     c.as1 = as1; c.one_tile = one_tile; c.debug = getenv("DAU_DOT_DEBUG") ? atoi(getenv("DAU_DOT_DEBUG")) : 0;
     *cfg = c;
     return true;
@@ -734,7 +736,7 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
         const size_t lds = (size_t)64 * (s.W | 1) * 4;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pack_error_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(pack_error_kernel, dim3(c.NP * g.nfb * g.EY), dim3(256), lds, st, dy, s.N, s.F, s.H, s.W, c.R, g.EX,
-                           g.EY, g.nfb, drop_col, drop_row, reinterpret_cast<float*>(ws + l.ep_off));
+                           g.EY, g.nfb, drop_col, drop_row, c.bf16 ? 1 : 0, reinterpret_cast<float*>(ws + l.ep_off));
     }
     {
         // channels beyond S (padding of the last input-channel block) must read as zero
@@ -745,7 +747,7 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         Blur4Args b{};
         b.in = x; b.taps = filters + kTaps1dOffset; b.xk = reinterpret_cast<float*>(ws + l.xk_off);
-        b.N = s.N; b.C = s.S; b.cstride = s_pad; b.H = s.H; b.W = s.W; b.k = c.blur_k; b.Hp = g.Hp; b.Wp = g.Wp;
+        b.N = s.N; b.C = s.S; b.cstride = s_pad; b.H = s.H; b.W = s.W; b.k = c.blur_k; b.Hp = g.Hp; b.Wp = g.Wp; b.bf16 = c.bf16 ? 1 : 0;
         b.WY = wy; b.WX = wx; b.nwy = (g.Hp + wy - 1) / wy; b.nwx = (g.Wp + wx - 1) / wx;
         hipLaunchKernelGGL(kern, dim3(c.NP * b.nwy * b.nwx * s.S), dim3(512), blur_lds, st, b);
     }

@@ -164,6 +164,7 @@ struct BlurPackArgs {
     const float* taps;
     float* staged;
     int mirrored, N, C, H, W, R, k;
+    int bf16;                   // input is bfloat16 (DAU_FLAG_IO_BF16)
     int cy, cx;                 // offset-window centre (0 unless the bucket is cut into windows)
     int ph, pw, npx, npy;
     int rows, pitch, cols, strip_cols;
@@ -199,8 +200,8 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
     auto gy = [&](int i) { return K ? gyr[i] : gyp[i]; };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int n0 = 2 * np, n1 = 2 * np + 1;
-    const float* p0 = a.in + ((long)n0 * C + c) * H * W;
-    const float* p1 = a.in + ((long)(n1 < a.N ? n1 : n0) * C + c) * H * W;
+    const long p0 = ((long)n0 * C + c) * H * W, p1 = ((long)(n1 < a.N ? n1 : n0) * C + c) * H * W;   // element offsets
+    const bool bf16 = a.bf16 != 0;
     const float m1 = n1 < a.N ? 1.0f : 0.0f;      // odd batch: the second image of the last pair is zero
     for (int r = wave; r < lh; r += nw) {
         const int yy = ya0 - kr + r;
@@ -208,7 +209,7 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
         for (int xl = lane; xl < lw; xl += 64) {
             const int xx = xa0 - kr + xl;
             f2 v = {0.0f, 0.0f};
-            if (rowin && xx >= 0 && xx < W) { v.x = p0[yy * W + xx]; v.y = m1 * p1[yy * W + xx]; }
+            if (rowin && xx >= 0 && xx < W) { v.x = load_act(a.in, p0 + yy * W + xx, bf16); v.y = m1 * load_act(a.in, p1 + yy * W + xx, bf16); }
             A[r * lw + xl] = v;
         }
     }
@@ -293,6 +294,7 @@ struct GatherArgs {
     unsigned strip_off;        // byte offset of the transposed strip inside a plane
     unsigned zpitch;           // epilogue Z-plane pitch (floats)
     int accumulate;            // 1: add to out (second and later offset-window passes)
+    int bf16;                  // out is bfloat16 (DAU_FLAG_IO_BF16)
     int debug;                 // timing experiments only (DAU_GATHER_DEBUG): 1 = no plane refills after the first two
 };
 
@@ -566,10 +568,8 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
                 const int gy = (patch / a.npx) * H + y, gx = (patch % a.npx) * W + x;    // non-EDGE: one patch, origin 0
                 const float* zf = zs + (size_t)kf * zchan + (unsigned)y * zpitch + x;
                 const float v = zf[0] + zf[zplane + 1] + zf[2 * zplane + zpitch] + zf[3 * zplane + zpitch + 1];
-                if (npp < npp_total && n < a.N && f < a.Cout && gy < a.H && gx < a.W) {
-                    float* dst = a.out + ((long)n * a.Cout + f) * plane_out + (long)gy * a.W + gx;
-                    *dst = a.accumulate ? *dst + v : v;
-                }
+                if (npp < npp_total && n < a.N && f < a.Cout && gy < a.H && gx < a.W)
+                    store_act(a.out, ((long)n * a.Cout + f) * plane_out + (long)gy * a.W + gx, v, a.bf16 != 0, a.accumulate != 0);
             }
         }
     }
@@ -615,7 +615,7 @@ size_t lds_bytes(const TiledConfig& c, const Geometry& g) {
 
 }  // namespace
 
-bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, TiledConfig* cfg) {
+bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, bool bf16, TiledConfig* cfg) {
     const Geometry g = make_geometry(H, W, R, G, N, Cout);
     if (g.variant < 0) return false;
     TiledConfig c{};
@@ -624,6 +624,7 @@ bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R
     c.rows = g.rows; c.pitch = g.pitch; c.tiles_x = g.tx; c.tiles_y = g.ty; c.fblock = g.fb; c.variant = g.variant;
     c.patches = g.npx * g.npy; c.stack = g.sk; c.windows = g.nwin1 * g.nwin1;
     c.debug = getenv("DAU_GATHER_DEBUG") ? atoi(getenv("DAU_GATHER_DEBUG")) : 0;
+    c.bf16 = bf16 ? 1 : 0;
     if (lds_bytes(c, g) > 160 * 1024) return false;
     // blur_pack keeps both raw planes (+ blur halo) and the horizontally filtered rows in LDS
     if (blur_pack_lds_bytes(g, blur_k) > 150 * 1024) return false;
@@ -653,7 +654,7 @@ void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in,
     // centre of this pass's offset window: staged (row, col) of a patch is the image at (py*ph - Rt + cy + row, ...)
     const int cy = -c.R + g.Rt + 2 * g.Rt * (window / g.nwin1), cx = -c.R + g.Rt + 2 * g.Rt * (window % g.nwin1);
     b.mirrored = mirrored ? 1 : 0; b.N = c.N; b.C = c.Cin; b.H = c.H; b.W = c.W; b.R = g.Rt; b.k = c.blur_k;
-    b.cy = cy; b.cx = cx;
+    b.cy = cy; b.cx = cx; b.bf16 = c.bf16;
     b.ph = g.ph; b.pw = g.pw; b.npx = g.npx; b.npy = g.npy;
     b.rows = g.rows; b.pitch = g.pitch; b.cols = g.cols; b.strip_cols = g.edge ? 2 * g.Rt + 1 : 0;
     b.plane_floats = g.plane_bytes / 4;
@@ -678,7 +679,7 @@ void tiled_gather_run(hipStream_t st, const TiledConfig& c, float* out, void* wo
     a.out = out;
     a.npx = g.npx; a.npy = g.npy;
     a.N = c.N; a.Cin = c.Cin; a.Cout = c.Cout; a.G = c.G; a.H = c.H; a.W = c.W; a.R = g.Rt;
-    a.accumulate = accumulate ? 1 : 0;
+    a.accumulate = accumulate ? 1 : 0; a.bf16 = c.bf16;
     a.nfb = (c.Cout + g.fb - 1) / g.fb;
     a.plane_bytes = (unsigned)g.plane_bytes;
     a.strip_off = (unsigned)g.strip_off;

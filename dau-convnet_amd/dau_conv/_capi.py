@@ -19,6 +19,7 @@ FLAG_USE_INTERPOLATION = 1 << 0
 FLAG_UNIT_TESTING = 1 << 1
 FLAG_SINGLE_DIM_KERNEL = 1 << 2
 FLAG_FORBID_POSITIVE_DIM1 = 1 << 3
+FLAG_IO_BF16 = 1 << 4   # x, y, dy, dx are torch.bfloat16; parameters and their gradients stay float32
 
 ALGO_AUTO, ALGO_DIRECT, ALGO_TILED = 0, 1, 2
 PASS_FORWARD, PASS_BACKWARD = 1, 2
@@ -102,9 +103,9 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _req(t, name, shape=None):
-    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
-        raise InvalidArgumentError("%s must be a contiguous float32 tensor on the GPU" % name)
+def _req(t, name, shape=None, dtype=torch.float32):
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise InvalidArgumentError("%s must be a contiguous %s tensor on the GPU" % (name, str(dtype).replace("torch.", "")))
     if shape is not None and tuple(t.shape) != tuple(shape):
         raise InvalidArgumentError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
     return t
@@ -120,6 +121,7 @@ class Plan(object):
         self._h = ctypes.c_void_p()
         _check(lib.dau_conv_plan_create(ctypes.byref(d), ctypes.byref(self._h)))
         self.N, self.S, self.F, self.G, self.H, self.W = N, S, F, G, H, W
+        self.io_dtype = torch.bfloat16 if int(flags) & FLAG_IO_BF16 else torch.float32
         info = _Info()
         _check(lib.dau_conv_plan_get_info(self._h, ctypes.byref(info)))
         self.info = {n: getattr(info, n) for n, _ in _Info._fields_}
@@ -146,10 +148,10 @@ class Plan(object):
 
     def forward(self, x, w, mu1, mu2, sigma):
         pshape = (1, self.S, self.G, self.F)
-        _req(x, "input", (self.N, self.S, self.H, self.W))
+        _req(x, "input", (self.N, self.S, self.H, self.W), self.io_dtype)
         for t, n in ((w, "weights"), (mu1, "mu1"), (mu2, "mu2"), (sigma, "sigma")):
             _req(t, n, pshape)
-        y = torch.empty((self.N, self.F, self.H, self.W), dtype=torch.float32, device=x.device)
+        y = torch.empty((self.N, self.F, self.H, self.W), dtype=self.io_dtype, device=x.device)
         ws = self._workspace(PASS_FORWARD, x.device)
         _check(lib.dau_conv_forward(self._h, _stream(), _ptr(x), _ptr(w), _ptr(mu1), _ptr(mu2), _ptr(sigma), _ptr(y),
                                     _ptr(ws), ws.numel()))
@@ -158,13 +160,13 @@ class Plan(object):
 
     def backward(self, x, dy, w, mu1, mu2, sigma, need_mask=NEED_ALL):
         pshape = (1, self.S, self.G, self.F)
-        _req(x, "input", (self.N, self.S, self.H, self.W))
-        _req(dy, "grad", (self.N, self.F, self.H, self.W))
+        _req(x, "input", (self.N, self.S, self.H, self.W), self.io_dtype)
+        _req(dy, "grad", (self.N, self.F, self.H, self.W), self.io_dtype)
         for t, n in ((w, "weights"), (mu1, "mu1"), (mu2, "mu2"), (sigma, "sigma")):
             _req(t, n, pshape)
         dev = x.device
         new = lambda shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        dx = new(x.shape) if need_mask & NEED_DX else None
+        dx = torch.empty(x.shape, dtype=self.io_dtype, device=dev) if need_mask & NEED_DX else None
         dw = new(pshape) if need_mask & NEED_DW else None
         dmu1 = new(pshape) if need_mask & NEED_DMU1 else None
         dmu2 = new(pshape) if need_mask & NEED_DMU2 else None

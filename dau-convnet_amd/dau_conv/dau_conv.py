@@ -57,6 +57,8 @@ def _get_plan(x, w, settings):
         flags |= _capi.FLAG_SINGLE_DIM_KERNEL
     if settings["forbid_positive_dim1"]:
         flags |= _capi.FLAG_FORBID_POSITIVE_DIM1
+    if x.dtype == torch.bfloat16:
+        flags |= _capi.FLAG_IO_BF16      # bfloat16 activations (input, output and their gradients); fp32 parameters
     key = (N, S, F, G, H, W, settings["kernel_size"], settings["number_units_ignore"], flags, settings["algo"],
            round(float(settings["sigma_hint"]), 6), float(settings["mu_learning_rate_factor"]), x.device.index)
     plan = _PLANS.get(key)

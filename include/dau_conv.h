@@ -73,6 +73,10 @@ enum {
                                                oracle rule (dau_conv_test.py:110-136)             */
     DAU_FLAG_SINGLE_DIM_KERNEL = 1 << 2,    /* attr single_dim_kernel (DAUConv1d)                 */
     DAU_FLAG_FORBID_POSITIVE_DIM1 = 1 << 3, /* attr forbid_positive_dim1                          */
+    DAU_FLAG_IO_BF16 = 1 << 4,              /* x, y, dy, dx are bfloat16 arrays (passed through the
+                                               float* parameters); parameters, their gradients and all
+                                               arithmetic stay fp32.  Needs the tiled kernels: plan
+                                               creation fails where only the direct ones apply.        */
     DAU_FLAG_DEFAULT = DAU_FLAG_USE_INTERPOLATION
 };
 
