@@ -16,8 +16,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_cpp_host_program_matches_oracle(tmp_path):
     exe = os.path.join(ROOT, "build", "cabi_host")
-    if not os.path.exists(exe):
-        pytest.fail("build/cabi_host is missing: run `python -c 'import __graft_entry__ as g; g.build()'` first")
+    if not os.path.exists(exe):      # normally built by __graft_entry__.build(); the GPU box has the same toolchain
+        os.makedirs(os.path.dirname(exe), exist_ok=True)
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "examples", "cabi_host.cpp"),
+                               "-L" + os.path.join(ROOT, "dau-convnet_amd", "dau_conv"), "-ldau_conv_hip",
+                               "-Wl,-rpath,$ORIGIN/../dau-convnet_amd/dau_conv", "-o", exe])
     out = str(tmp_path / "out.bin")
     r = subprocess.run([exe, out], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
