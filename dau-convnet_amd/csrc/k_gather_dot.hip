@@ -111,10 +111,14 @@ DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one
     // per pass: enough workgroups to fill the chip several times over, but no more chunks than items
     g.chunks = 1;
     for (int i = 0; i < g.npass; ++i) {
+        // at most four full rounds of 256 workgroups (one more workgroup would add a whole, nearly empty round), no
+        // more chunks than items, and no chunk without items
         const int per_chunk = g.nfb * g.pass[i].nsb * g.pass[i].ngb * g.nsub1 * g.nsub1;
-        int chunks = (256 * 4 + per_chunk - 1) / per_chunk;
+        int chunks = (256 * 4) / per_chunk;
         if (chunks > g.items) chunks = g.items;
         if (chunks < 1) chunks = 1;
+        const int per = (g.items + chunks - 1) / chunks;
+        chunks = (g.items + per - 1) / per;
         g.pass[i].chunks = chunks;
         if (chunks > g.chunks) g.chunks = chunks;           // slabs allocated for the partial sums
     }
