@@ -43,7 +43,8 @@ typedef __attribute__((address_space(1))) const void* glb_ptr_t;
 namespace {
 
 constexpr int kDF = 32;        // output channels per workgroup (half a wave; the two halves are two units g)
-constexpr int kRW = 8, kRH = 8;  // region of positions q handled per item
+constexpr int kRW = 8;           // region of positions q handled per item: kRW columns x RH rows (RH = 8, or 7 for heights
+                                 // such as 7, 14, 28 that waste fewer rows that way)
 #ifndef DAU_DOT_WAVES
 #define DAU_DOT_WAVES 16
 #endif
@@ -53,6 +54,7 @@ constexpr int kParamDwords = 8;  // per lane per (s, g-pair): b00,b01,b10,b11, b
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct DotGeometry {
+    int RH;                     // rows per region: 8 or 7
     int epitch, erows;          // LDS error tile (positions)
     int rx, ry;                 // regions per image
     int EX, EY;                 // staged error plane (positions): regions*8 + 2R + 1
@@ -78,12 +80,14 @@ DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one
     g.Rt = R < 8 ? R : 8;
     g.nsub1 = R / g.Rt;
     g.epitch = kRW + 2 * g.Rt + 1;
-    g.erows = kRH + 2 * g.Rt + 1;
+    // rows per region: 7 when that pads the height less (7, 14, 21, 27, 28, ...)
+    g.RH = ((sh.H + 6) / 7) * 7 < ((sh.H + 7) / 8) * 8 ? 7 : 8;
+    g.erows = g.RH + 2 * g.Rt + 1;
     g.rx = (sh.W + kRW - 1) / kRW;
-    g.ry = (sh.H + kRH - 1) / kRH;
+    g.ry = (sh.H + g.RH - 1) / g.RH;
     g.EX = g.rx * kRW + 2 * R + 1;
-    g.EY = g.ry * kRH + 2 * R + 1;
-    g.Hp = g.ry * kRH;
+    g.EY = g.ry * g.RH + 2 * R + 1;
+    g.Hp = g.ry * g.RH;
     g.Wp = g.rx * kRW;
     g.nfb = (sh.F + kDF - 1) / kDF;
     {
@@ -359,10 +363,12 @@ __device__ __forceinline__ f4 mfma_bcast(float a, float b, f4 c, int abid) {
     }
 }
 
-constexpr int kXSlots = kRH / 2;   // Xk ring: one slot = two region rows = 16 positions
-
-template <int GP, int AS>
+// RH rows per region; the Xk ring has one slot per two region rows = 16 positions (the last slot of an odd RH fetches one
+// row too many, which is never used; the buffer has a spare row at its end)
+template <int GP, int AS, int RH>
 __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) gather_dot_kernel(const DotArgs a) {
+    constexpr int kRH = RH;
+    constexpr int kXSlots = (RH + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -629,7 +635,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     // the row pair is consumed: refill its slot with the same rows of the next sweep
-                    if (j % 2 == 1 && gq + 1 == kGroups) x_load(xr[j / 2], xlane, xnext_sweep + (j - 1) * xpitch, 0);
+                    if ((j % 2 == 1 || j + 1 == kRH) && gq + 1 == kGroups) x_load(xr[j / 2], xlane, xnext_sweep + (j / 2) * 2 * xpitch, 0);
                     lgkm_wait0();   // the prefetched group has landed
                 }
                 // next row: tile rows shift down by one
@@ -675,7 +681,7 @@ DotLayout dot_layout(const TiledDotConfig& c, const DotGeometry& g) {
     const size_t s_pad = (size_t)g.s_pad;
     size_t off = 0;
     l.ep_off = off; off += round_up(NP * g.nfb * g.EY * g.EX * kDF * 8, 256);
-    l.xk_off = off; off += round_up(NP * s_pad * g.Hp * g.Wp * 32, 256);
+    l.xk_off = off; off += round_up(NP * s_pad * g.Hp * g.Wp * 32 + (size_t)g.Wp * 32, 256);   // + one spare row
     const size_t nsub = (size_t)g.nsub1 * g.nsub1;
     l.params_off = off;
     for (int i = 0; i < g.npass; ++i) off += g.pass[i].params_bytes;
@@ -694,9 +700,9 @@ void blur4_plan(int k, int Hp, int Wp, int* wy, int* wx, size_t* lds) {
     *wy = WY; *wx = WX; *lds = bytes(WY);
 }
 
-template <int GP, int AS>
+template <int GP, int AS, int RH>
 void launch_dot(hipStream_t st, const DotArgs& a, int grid, size_t lds) {
-    auto kern = gather_dot_kernel<GP, AS>;
+    auto kern = gather_dot_kernel<GP, AS, RH>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kDWaves * 64), lds, st, a);
 }
@@ -786,9 +792,15 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
         a.params = reinterpret_cast<const float*>(ws + l.params_off + ps.params_off);
         a.g_begin = ps.g_begin; a.nsb = ps.nsb; a.ngb = ps.ngb; a.chunks = ps.chunks;
         const int grid = ps.chunks * g.nsub1 * g.nsub1 * g.nfb * ps.ngb * ps.nsb;
-        if (ps.GP == 1) launch_dot<1, 4>(st, a, grid, lds);
-        else if (ps.AS == 2) launch_dot<2, 2>(st, a, grid, lds);
-        else launch_dot<2, 1>(st, a, grid, lds);
+        if (g.RH == 8) {
+            if (ps.GP == 1) launch_dot<1, 4, 8>(st, a, grid, lds);
+            else if (ps.AS == 2) launch_dot<2, 2, 8>(st, a, grid, lds);
+            else launch_dot<2, 1, 8>(st, a, grid, lds);
+        } else {
+            if (ps.GP == 1) launch_dot<1, 4, 7>(st, a, grid, lds);
+            else if (ps.AS == 2) launch_dot<2, 2, 7>(st, a, grid, lds);
+            else launch_dot<2, 1, 7>(st, a, grid, lds);
+        }
     }
     const long n = (long)kNumK * s.S * s.G * s.F;
     const int rgrid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
