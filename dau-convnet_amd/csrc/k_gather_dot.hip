@@ -453,9 +453,10 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
             unsigned piece = r * kDWaves + wave;
             if (piece >= kPieces4) piece -= kDWaves;
             const unsigned b = piece * 1024 + lane * 16;
-            unsigned trow = b / row_bytes;
-            const unsigned within = b - trow * row_bytes;
-            if (trow >= (unsigned)a.erows) trow = a.erows - 1;
+            constexpr unsigned kRowBytes4 = (kRW + 2 * 4 + 1) * kDF * 8, kRows4 = kRH + 2 * 4 + 1;   // the R = 4 tile
+            unsigned trow = b / kRowBytes4;                                                           // constant divisor
+            const unsigned within = b - trow * kRowBytes4;
+            if (trow >= kRows4) trow = kRows4 - 1;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)trow * a.EX * (kDF * 8) + within),
                                              (lds_ptr_t)(smem + buf * tile_bytes + piece * 1024), 16, 0, 0);
         }
