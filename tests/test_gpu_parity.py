@@ -128,6 +128,14 @@ def test_filter_synthesis(sigma, sd, fp):
         assert_parity(got[i], want[name], name, rel=1e-6, floor=1e-7)
 
 
+def test_zero_sized_dimensions_are_rejected():
+    from dau_conv import _capi
+    for bad in (dict(N=0), dict(S=0), dict(F=0), dict(G=0), dict(H=0), dict(W=0)):
+        kw = dict(N=2, S=3, F=4, G=2, H=8, W=8); kw.update(bad)
+        with pytest.raises(_capi.InvalidArgumentError):
+            _capi.Plan(kw["N"], kw["S"], kw["F"], kw["G"], kw["H"], kw["W"])
+
+
 def test_error_convention():
     """NaN offsets -> FAILED_PRECONDITION, offsets beyond the kernel -> INVALID_ARGUMENT
     (dau_conv_op.cpp:250-262); wrong shapes are rejected before any launch."""
@@ -181,6 +189,10 @@ def test_error_convention():
     # offset windows of the gather-dot for kernels 33 and 65 with offsets over the whole range
     dict(N=2, W=40, H=40, S=5, F=33, G=3, k=33, m=16),
     dict(N=1, W=48, H=40, S=3, F=8, G=2, k=65, m=32),
+    # degenerate sizes: one pixel, one channel, one unit; a 2x3 image
+    dict(N=1, W=1, H=1, S=1, F=1, G=1, k=9, m=3),
+    dict(N=3, W=3, H=2, S=2, F=3, G=2, k=9, m=3),
+    dict(N=1, W=9, H=1, S=3, F=2, G=4, k=17, m=7),
     # gather-dot passes: 5 = 4 + 1, 7 = 4 + 3 (two four-unit blocks), 9 = 8 + 1, 10 = 8 + 2 units; odd channel counts
     dict(N=2, W=16, H=24, S=35, F=33, G=5, k=9, m=3),
     dict(N=2, W=16, H=16, S=9, F=40, G=7, k=9, m=3),
