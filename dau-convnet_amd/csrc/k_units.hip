@@ -28,10 +28,13 @@ __global__ void prepare_units_kernel(const float* __restrict__ w, const float* _
                                      UnitRef* __restrict__ table, Status* __restrict__ status) {
     const long units = (long)S * G * F;
     unsigned int local_max = 0, local_nan = 0;
-    for (long u = blockIdx.x * (long)blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
-        const int f = (int)(u % F);
-        const int g = (int)((u / F) % G);
-        const int s = (int)(u / ((long)F * G));
+    // the loop index is the DESTINATION slot, so that the 24-byte table entries are written in order; in the transposed
+    // case the three parameter reads are the strided side instead (12 B per unit, served from L2)
+    for (long dst = blockIdx.x * (long)blockDim.x + threadIdx.x; dst < units; dst += (long)gridDim.x * blockDim.x) {
+        int f, g, s;
+        if (transposed_negated) { s = (int)(dst % S); g = (int)((dst / S) % G); f = (int)(dst / ((long)S * G)); }
+        else { f = (int)(dst % F); g = (int)((dst / F) % G); s = (int)(dst / ((long)F * G)); }
+        const long u = ((long)s * G + g) * F + f;
         float m1 = mu1[u], m2 = mu2[u];
         const bool is_nan = (m1 != m1) || (m2 != m2);
         if (is_nan) { local_nan = 1; m1 = 0.0f; m2 = 0.0f; }
@@ -49,15 +52,20 @@ __global__ void prepare_units_kernel(const float* __restrict__ w, const float* _
         r.ox = ox; r.oy = oy;
         // premultiplied tap weights (dau_conv_forward_core.hpp:2155-2213)
         r.w00 = wv * b00; r.w01 = wv * b01; r.w10 = wv * b10; r.w11 = wv * b11;
-        const long dst = transposed_negated ? ((long)f * G + g) * S + s : u;
         table[dst] = r;
     }
     if (status) {
+        // one atomic per workgroup: thousands of same-address atomics serialise in L2 and were most of this kernel's time
+        __shared__ unsigned int smax[16], snan[16];
         for (int m = 32; m >= 1; m >>= 1) {
             local_max = max(local_max, (unsigned int)__shfl_xor((int)local_max, m));
             local_nan |= (unsigned int)__shfl_xor((int)local_nan, m);
         }
-        if ((threadIdx.x & 63) == 0) {
+        const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+        if ((threadIdx.x & 63) == 0) { smax[wave] = local_max; snan[wave] = local_nan; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 1; i < nw; ++i) { local_max = max(local_max, smax[i]); local_nan |= snan[i]; }
             atomicMax(&status->max_abs_mu_bits, local_max);
             if (local_nan) atomicOr(&status->nan_seen, 1u);
         }
@@ -69,7 +77,7 @@ void launch_prepare_units(hipStream_t st, const float* w, const float* mu1, cons
                           Status* status) {
     const long units = (long)sh.S * sh.G * sh.F;
     const int block = 256;
-    const int grid = (int)((units + block - 1) / block < 2048 ? (units + block - 1) / block : 2048);
+    const int grid = (int)((units + block - 1) / block < 512 ? (units + block - 1) / block : 512);
     hipLaunchKernelGGL(prepare_units_kernel, dim3(grid), dim3(block), 0, st, w, mu1, mu2, sh.S, sh.G, sh.F,
                        ignore, flags, bucket, transposed_negated ? 1 : 0, w == nullptr ? 1 : 0, table, status);
 }
