@@ -178,6 +178,8 @@ struct Blur4Args {
     float* xk;
     int N, C, cstride, H, W, k, Hp, Wp;
     int bf16;                   // input is bfloat16
+    int ppb, items;             // windows per workgroup (small maps) and windows in total
+    unsigned lds_item_floats;   // LDS floats per window
     int WY, WX, nwy, nwx;       // output window (rows x columns of the Hp x Wp plane) and windows per plane
 };
 
@@ -186,7 +188,12 @@ template <int K>
 __global__ void __launch_bounds__(512) blur4_pack_kernel(const Blur4Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int C = a.C, H = a.H, W = a.W, k = K ? K : a.k;
-    int t = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int nw = (blockDim.x >> 6) / a.ppb;     // waves per window
+    const int sub = (threadIdx.x >> 6) / nw, wave = (threadIdx.x >> 6) % nw;
+    int t = blockIdx.x * a.ppb + sub;
+    const bool active = t < a.items;              // idle wave groups of the last workgroup still reach the barriers
+    if (!active) t = a.items - 1;
     const int c = t % C; t /= C;
     const int wx = t % a.nwx; t /= a.nwx;
     const int wy = t % a.nwy;
@@ -195,7 +202,7 @@ __global__ void __launch_bounds__(512) blur4_pack_kernel(const Blur4Args a) {
     const int oh = oy0 + a.WY < a.Hp ? a.WY : a.Hp - oy0, ow = ox0 + a.WX < a.Wp ? a.WX : a.Wp - ox0;
     const int kr = (k - 1) / 2;
     const int lw = ow + 2 * kr, lh = oh + 2 * kr;
-    f2* A = reinterpret_cast<f2*>(lds);                      // raw [lh][lw], image (oy0 - kr + r, ox0 - kr + xl)
+    f2* A = reinterpret_cast<f2*>(lds + (size_t)sub * a.lds_item_floats);   // raw [lh][lw], image (oy0 - kr + r, ox0 - kr + xl)
     f2* B = A + (size_t)lh * lw;                             // [3][lh][ow]
     const float* tp[6] = {a.taps + kTapGX * kTapPitch, a.taps + kTapAX * kTapPitch, a.taps + kTapCX * kTapPitch,
                           a.taps + kTapGY * kTapPitch, a.taps + kTapAY * kTapPitch, a.taps + kTapBY * kTapPitch};
@@ -207,7 +214,6 @@ __global__ void __launch_bounds__(512) blur4_pack_kernel(const Blur4Args a) {
             for (int i = 0; i < K; ++i) tr[q][i] = tp[q][i];
     }
     auto tap = [&](int q, int i) { return K ? tr[q][i] : tp[q][i]; };
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int n0 = 2 * np, n1 = 2 * np + 1;
     const long p0 = ((long)n0 * C + c) * H * W, p1 = ((long)(n1 < a.N ? n1 : n0) * C + c) * H * W;   // element offsets
     const bool bf16 = a.bf16 != 0;
@@ -242,7 +248,7 @@ __global__ void __launch_bounds__(512) blur4_pack_kernel(const Blur4Args a) {
     }
     __syncthreads();
     f8* out = reinterpret_cast<f8*>(a.xk) + ((size_t)np * a.cstride + c) * a.Hp * a.Wp;
-    for (int yr = wave; yr < oh; yr += nw) {
+    for (int yr = active ? wave : oh; yr < oh; yr += nw) {
         const int yy = oy0 + yr;
         for (int xc = lane; xc < ow; xc += 64) {
             const int xx = ox0 + xc;
@@ -760,7 +766,13 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
         b.in = x; b.taps = filters + kTaps1dOffset; b.xk = reinterpret_cast<float*>(ws + l.xk_off);
         b.N = s.N; b.C = s.S; b.cstride = s_pad; b.H = s.H; b.W = s.W; b.k = c.blur_k; b.Hp = g.Hp; b.Wp = g.Wp; b.bf16 = c.bf16 ? 1 : 0;
         b.WY = wy; b.WX = wx; b.nwy = (g.Hp + wy - 1) / wy; b.nwx = (g.Wp + wx - 1) / wx;
-        hipLaunchKernelGGL(kern, dim3(c.NP * b.nwy * b.nwx * s.S), dim3(512), blur_lds, st, b);
+        // small windows: several per workgroup, so that the 512 threads have rows to share
+        const int elems = wy * wx;
+        b.ppb = elems >= 2048 ? 1 : elems >= 1024 ? 2 : elems >= 512 ? 4 : 8;
+        while (b.ppb > 1 && b.ppb * blur_lds > 64 * 1024) b.ppb /= 2;
+        b.items = c.NP * b.nwy * b.nwx * s.S;
+        b.lds_item_floats = (unsigned)(blur_lds / 4);
+        hipLaunchKernelGGL(kern, dim3((b.items + b.ppb - 1) / b.ppb), dim3(512), b.ppb * blur_lds, st, b);
     }
     for (int i = 0; i < g.npass; ++i) {
         const DotGeometry::Pass& ps = g.pass[i];

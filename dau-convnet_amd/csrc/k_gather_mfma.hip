@@ -169,6 +169,9 @@ struct BlurPackArgs {
     int ph, pw, npx, npy;
     int rows, pitch, cols, strip_cols;
     size_t plane_floats;
+    int ppb;                    // planes per workgroup (small planes: every group of 8/ppb waves blurs its own plane)
+    int planes;                 // (image pair, patch, channel) planes in total
+    unsigned lds_plane_floats;  // LDS floats per plane
 };
 
 // K: compile-time prefilter support (taps live in SGPRs, tap loops unrolled); K = 0: any support, taps re-read per use
@@ -176,8 +179,14 @@ template <int K>
 __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int C = a.C, H = a.H, W = a.W, R = a.R, k = K ? K : a.k;
-    const int c = blockIdx.x % C;
-    const int npp = blockIdx.x / C;                // (image pair, patch)
+    const int lane = threadIdx.x & 63;
+    const int nw = (blockDim.x >> 6) / a.ppb;     // waves per plane
+    const int sub = (threadIdx.x >> 6) / nw, wave = (threadIdx.x >> 6) % nw;
+    int pid = blockIdx.x * a.ppb + sub;
+    const bool active = pid < a.planes;           // the last workgroup may have idle wave groups (they still reach the barriers)
+    if (!active) pid = a.planes - 1;
+    const int c = pid % C;
+    const int npp = pid / C;                       // (image pair, patch)
     const int npatch = a.npx * a.npy;
     const int np = npp / npatch, patch = npp % npatch;
     const int wy0 = (patch / a.npx) * a.ph - R + a.cy, wx0 = (patch % a.npx) * a.pw - R + a.cx;   // image coordinates of staged (0, 0)
@@ -187,7 +196,7 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
     const int kr = (k - 1) / 2;
     const int bw = xa1 - xa0;
     const int lw = bw + 2 * kr, lh = (ya1 - ya0) + 2 * kr;
-    f2* A = reinterpret_cast<f2*>(lds);          // raw window, zero outside the image   [lh][lw]
+    f2* A = reinterpret_cast<f2*>(lds + (size_t)sub * a.lds_plane_floats);   // raw window, zero outside the image   [lh][lw]
     f2* B = A + (size_t)lh * lw;                  // after the horizontal pass            [lh][bw]
     const float* gxp = a.taps + (a.mirrored ? kTapGXR : kTapGX) * kTapPitch;
     const float* gyp = a.taps + (a.mirrored ? kTapGYR : kTapGY) * kTapPitch;
@@ -198,7 +207,6 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
     }
     auto gx = [&](int i) { return K ? gxr[i] : gxp[i]; };
     auto gy = [&](int i) { return K ? gyr[i] : gyp[i]; };
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int n0 = 2 * np, n1 = 2 * np + 1;
     const long p0 = ((long)n0 * C + c) * H * W, p1 = ((long)(n1 < a.N ? n1 : n0) * C + c) * H * W;   // element offsets
     const bool bf16 = a.bf16 != 0;
@@ -229,7 +237,7 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
     __syncthreads();
     f2* out = reinterpret_cast<f2*>(a.staged + ((size_t)npp * C + c) * a.plane_floats);
     f2* strip = out + (size_t)a.rows * a.pitch;
-    for (int row = wave; row < a.rows; row += nw) {
+    for (int row = active ? wave : a.rows; row < a.rows; row += nw) {
         const int iy = wy0 + row;
         const bool rowin = iy >= ya0 && iy < ya1;
         for (int col = lane; col < a.pitch; col += 64) {
@@ -658,7 +666,13 @@ void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in,
     b.ph = g.ph; b.pw = g.pw; b.npx = g.npx; b.npy = g.npy;
     b.rows = g.rows; b.pitch = g.pitch; b.cols = g.cols; b.strip_cols = g.edge ? 2 * g.Rt + 1 : 0;
     b.plane_floats = g.plane_bytes / 4;
-    hipLaunchKernelGGL(kern, dim3(c.NP * c.patches * c.Cin), dim3(512), blur_lds, st, b);
+    // small planes: several per workgroup, so that the 512 threads have rows to share (7x7 maps: 8 planes)
+    const int elems = g.rows * g.pitch;
+    b.ppb = elems >= 4096 ? 1 : elems >= 2048 ? 2 : elems >= 1024 ? 4 : 8;
+    while (b.ppb > 1 && b.ppb * blur_lds > 64 * 1024) b.ppb /= 2;
+    b.planes = c.NP * c.patches * c.Cin;
+    b.lds_plane_floats = (unsigned)(blur_lds / 4);
+    hipLaunchKernelGGL(kern, dim3((b.planes + b.ppb - 1) / b.ppb), dim3(512), b.ppb * blur_lds, st, b);
     const int nfb = (c.Cout + g.fb - 1) / g.fb;
     const size_t uts = ut_stride_bytes(c.G, g.fb);
     // packed slices are padded to whole KiB; zero the padding once per call together with the payload
