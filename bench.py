@@ -79,7 +79,18 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL prints a version banner on stdout when the communicator is created; stdout is reserved for the one
+        # JSON line, so the banner goes to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     from dau_conv import _capi
 
