@@ -129,7 +129,7 @@ class Plan(object):
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and lib is not None:        # at interpreter shutdown the module globals may already be gone
             lib.dau_conv_plan_destroy(h)
             self._h = None
 
