@@ -149,15 +149,16 @@ __global__ void __launch_bounds__(256) pack_error_kernel(const float* __restrict
     const int fb = (blockIdx.x / EY) % nfb;
     const int np = blockIdx.x / (EY * nfb);
     const int y = Y - (R + 1);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int wp = W | 1;                                   // odd pitch: conflict-free transposed reads
     const bool rowin = y >= 0 && y < H && !(drop_row && y == H - 1);
     if (rowin) {
-        for (int r = wave; r < 64; r += nw) {               // r = fl*2 + image
+        // flat over (r = fl*2 + image, x): narrow maps keep all lanes busy (a 7-pixel row per wave instruction did not)
+        for (int t = threadIdx.x; t < 64 * W; t += blockDim.x) {
+            const int r = t / W, x = t - r * W;
             const int f = fb * kDF + (r >> 1), n = 2 * np + (r & 1);
             const bool ok = f < F && n < N;
             const long src = (((long)(ok ? n : 0) * F + (ok ? f : 0)) * H + y) * W;
-            for (int x = lane; x < W; x += 64) lds[r * wp + x] = ok ? load_act(dy, src + x, bf16 != 0) : 0.0f;
+            lds[r * wp + x] = ok ? load_act(dy, src + x, bf16 != 0) : 0.0f;
         }
     }
     __syncthreads();
