@@ -211,48 +211,47 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
     const long p0 = ((long)n0 * C + c) * H * W, p1 = ((long)(n1 < a.N ? n1 : n0) * C + c) * H * W;   // element offsets
     const bool bf16 = a.bf16 != 0;
     const float m1 = n1 < a.N ? 1.0f : 0.0f;      // odd batch: the second image of the last pair is zero
-    for (int r = wave; r < lh; r += nw) {
-        const int yy = ya0 - kr + r;
-        const bool rowin = yy >= 0 && yy < H;
-        for (int xl = lane; xl < lw; xl += 64) {
-            const int xx = xa0 - kr + xl;
-            f2 v = {0.0f, 0.0f};
-            if (rowin && xx >= 0 && xx < W) { v.x = load_act(a.in, p0 + yy * W + xx, bf16); v.y = m1 * load_act(a.in, p1 + yy * W + xx, bf16); }
-            A[r * lw + xl] = v;
+    // rows x cols of work for this plane's waves: a wave per row when the rows are wide, a flat index when they are narrow
+    // (a 7-pixel row would leave most of a wave idle)
+    auto for_each = [&](int rows_, int cols_, auto&& body) {
+        if (cols_ >= 56) {
+            for (int r = wave; r < rows_; r += nw)
+                for (int x = lane; x < cols_; x += 64) body(r, x);
+        } else {
+            for (int t = wave * 64 + lane; t < rows_ * cols_; t += nw * 64) { const int r = t / cols_; body(r, t - r * cols_); }
         }
-    }
+    };
+    for_each(lh, lw, [&](int r, int xl) {
+        const int yy = ya0 - kr + r, xx = xa0 - kr + xl;
+        f2 v = {0.0f, 0.0f};
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) { v.x = load_act(a.in, p0 + yy * W + xx, bf16); v.y = m1 * load_act(a.in, p1 + yy * W + xx, bf16); }
+        A[r * lw + xl] = v;
+    });
     __syncthreads();
-    for (int r = wave; r < lh; r += nw) {
+    for_each(lh, bw, [&](int r, int x) {
         const int yy = ya0 - kr + r;
-        const bool rowin = yy >= 0 && yy < H;
-        for (int x = lane; x < bw; x += 64) {
-            f2 acc = {0.0f, 0.0f};
-            if (rowin) {
+        f2 acc = {0.0f, 0.0f};
+        if (yy >= 0 && yy < H) {
 #pragma unroll
-                for (int i = 0; i < k; ++i) acc = __builtin_elementwise_fma(A[r * lw + x + i], f2{gx(i), gx(i)}, acc);
-            }
-            B[r * bw + x] = acc;
+            for (int i = 0; i < k; ++i) acc = __builtin_elementwise_fma(A[r * lw + x + i], f2{gx(i), gx(i)}, acc);
         }
-    }
+        B[r * bw + x] = acc;
+    });
     __syncthreads();
     f2* out = reinterpret_cast<f2*>(a.staged + ((size_t)npp * C + c) * a.plane_floats);
     f2* strip = out + (size_t)a.rows * a.pitch;
-    for (int row = active ? wave : a.rows; row < a.rows; row += nw) {
-        const int iy = wy0 + row;
-        const bool rowin = iy >= ya0 && iy < ya1;
-        for (int col = lane; col < a.pitch; col += 64) {
-            const int ix = wx0 + col;
-            f2 acc = {0.0f, 0.0f};
-            if (rowin && ix >= xa0 && ix < xa1) {
+    for_each(active ? a.rows : 0, a.pitch, [&](int row, int col) {
+        const int iy = wy0 + row, ix = wx0 + col;
+        f2 acc = {0.0f, 0.0f};
+        if (iy >= ya0 && iy < ya1 && ix >= xa0 && ix < xa1) {
 #pragma unroll
-                for (int j = 0; j < k; ++j) acc = __builtin_elementwise_fma(B[(iy - ya0 + j) * bw + (ix - xa0)], f2{gy(j), gy(j)}, acc);
-            }
-            out[row * a.pitch + col] = acc;
-            // columns pw .. pw+2R are stored a second time column-major: the edge-column tile of the gather reads a
-            // vertical run of positions, which is bank-conflict free only in this orientation
-            if (a.strip_cols > 0 && col >= a.pw && col < a.pw + a.strip_cols) strip[(col - a.pw) * a.rows + row] = acc;
+            for (int j = 0; j < k; ++j) acc = __builtin_elementwise_fma(B[(iy - ya0 + j) * bw + (ix - xa0)], f2{gy(j), gy(j)}, acc);
         }
-    }
+        out[row * a.pitch + col] = acc;
+        // columns pw .. pw+2R are stored a second time column-major: the edge-column tile of the gather reads a
+        // vertical run of positions, which is bank-conflict free only in this orientation
+        if (a.strip_cols > 0 && col >= a.pw && col < a.pw + a.strip_cols) strip[(col - a.pw) * a.rows + row] = acc;
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
