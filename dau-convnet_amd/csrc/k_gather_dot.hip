@@ -219,55 +219,54 @@ __global__ void __launch_bounds__(512) blur4_pack_kernel(const Blur4Args a) {
     const long p0 = ((long)n0 * C + c) * H * W, p1 = ((long)(n1 < a.N ? n1 : n0) * C + c) * H * W;   // element offsets
     const bool bf16 = a.bf16 != 0;
     const float m1 = n1 < a.N ? 1.0f : 0.0f;
-    for (int r = wave; r < lh; r += nw) {
-        const int yy = oy0 - kr + r;
-        const bool rowin = yy >= 0 && yy < H;
-        for (int xl = lane; xl < lw; xl += 64) {
-            const int xx = ox0 - kr + xl;
-            f2 v = {0.0f, 0.0f};
-            if (rowin && xx >= 0 && xx < W) { v.x = load_act(a.in, p0 + yy * W + xx, bf16); v.y = m1 * load_act(a.in, p1 + yy * W + xx, bf16); }
-            A[r * lw + xl] = v;
+    // rows x cols of work for this window's waves: a wave per row when the rows are wide, a flat index when they are narrow
+    auto for_each = [&](int rows_, int cols_, auto&& body) {
+        if (cols_ >= 56) {
+            for (int r = wave; r < rows_; r += nw)
+                for (int x = lane; x < cols_; x += 64) body(r, x);
+        } else {
+            for (int t = wave * 64 + lane; t < rows_ * cols_; t += nw * 64) { const int r = t / cols_; body(r, t - r * cols_); }
         }
-    }
+    };
+    for_each(lh, lw, [&](int r, int xl) {
+        const int yy = oy0 - kr + r, xx = ox0 - kr + xl;
+        f2 v = {0.0f, 0.0f};
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) { v.x = load_act(a.in, p0 + yy * W + xx, bf16); v.y = m1 * load_act(a.in, p1 + yy * W + xx, bf16); }
+        A[r * lw + xl] = v;
+    });
     __syncthreads();
-    for (int r = wave; r < lh; r += nw) {
+    for_each(lh, ow, [&](int r, int x) {
         const int yy = oy0 - kr + r;
-        const bool rowin = yy >= 0 && yy < H;
-        for (int x = lane; x < ow; x += 64) {
-            f2 h1 = {0.0f, 0.0f}, h2 = {0.0f, 0.0f}, h3 = {0.0f, 0.0f};
-            if (rowin) {
+        f2 h1 = {0.0f, 0.0f}, h2 = {0.0f, 0.0f}, h3 = {0.0f, 0.0f};
+        if (yy >= 0 && yy < H) {
 #pragma unroll
-                for (int i = 0; i < k; ++i) {
-                    const f2 v = A[r * lw + x + i];
-                    h1 = __builtin_elementwise_fma(v, f2{tap(0, i), tap(0, i)}, h1);
-                    h2 = __builtin_elementwise_fma(v, f2{tap(1, i), tap(1, i)}, h2);
-                    h3 = __builtin_elementwise_fma(v, f2{tap(2, i), tap(2, i)}, h3);
-                }
+            for (int i = 0; i < k; ++i) {
+                const f2 v = A[r * lw + x + i];
+                h1 = __builtin_elementwise_fma(v, f2{tap(0, i), tap(0, i)}, h1);
+                h2 = __builtin_elementwise_fma(v, f2{tap(1, i), tap(1, i)}, h2);
+                h3 = __builtin_elementwise_fma(v, f2{tap(2, i), tap(2, i)}, h3);
             }
-            B[(0 * lh + r) * ow + x] = h1; B[(1 * lh + r) * ow + x] = h2; B[(2 * lh + r) * ow + x] = h3;
         }
-    }
+        B[(0 * lh + r) * ow + x] = h1; B[(1 * lh + r) * ow + x] = h2; B[(2 * lh + r) * ow + x] = h3;
+    });
     __syncthreads();
     f8* out = reinterpret_cast<f8*>(a.xk) + ((size_t)np * a.cstride + c) * a.Hp * a.Wp;
-    for (int yr = active ? wave : oh; yr < oh; yr += nw) {
-        const int yy = oy0 + yr;
-        for (int xc = lane; xc < ow; xc += 64) {
-            const int xx = ox0 + xc;
-            f2 dw = {0.0f, 0.0f}, d1 = {0.0f, 0.0f}, d2 = {0.0f, 0.0f}, ds = {0.0f, 0.0f};
-            if (yy < H && xx < W) {
+    for_each(active ? oh : 0, ow, [&](int yr, int xc) {
+        const int yy = oy0 + yr, xx = ox0 + xc;
+        f2 dw = {0.0f, 0.0f}, d1 = {0.0f, 0.0f}, d2 = {0.0f, 0.0f}, ds = {0.0f, 0.0f};
+        if (yy < H && xx < W) {
 #pragma unroll
-                for (int j = 0; j < k; ++j) {
-                    const f2 b1 = B[(0 * lh + yr + j) * ow + xc], b2 = B[(1 * lh + yr + j) * ow + xc], b3 = B[(2 * lh + yr + j) * ow + xc];
-                    dw = __builtin_elementwise_fma(b1, f2{tap(3, j), tap(3, j)}, dw);
-                    d1 = __builtin_elementwise_fma(b2, f2{tap(3, j), tap(3, j)}, d1);
-                    d2 = __builtin_elementwise_fma(b1, f2{tap(4, j), tap(4, j)}, d2);
-                    ds = __builtin_elementwise_fma(b3, f2{tap(3, j), tap(3, j)}, ds);
-                    ds = __builtin_elementwise_fma(b1, f2{tap(5, j), tap(5, j)}, ds);
-                }
+            for (int j = 0; j < k; ++j) {
+                const f2 b1 = B[(0 * lh + yr + j) * ow + xc], b2 = B[(1 * lh + yr + j) * ow + xc], b3 = B[(2 * lh + yr + j) * ow + xc];
+                dw = __builtin_elementwise_fma(b1, f2{tap(3, j), tap(3, j)}, dw);
+                d1 = __builtin_elementwise_fma(b2, f2{tap(3, j), tap(3, j)}, d1);
+                d2 = __builtin_elementwise_fma(b1, f2{tap(4, j), tap(4, j)}, d2);
+                ds = __builtin_elementwise_fma(b3, f2{tap(3, j), tap(3, j)}, ds);
+                ds = __builtin_elementwise_fma(b1, f2{tap(5, j), tap(5, j)}, ds);
             }
-            out[(size_t)yy * a.Wp + xx] = f8{dw.x, dw.y, d1.x, d1.y, d2.x, d2.y, ds.x, ds.y};
         }
-    }
+        out[(size_t)yy * a.Wp + xx] = f8{dw.x, dw.y, d1.x, d1.y, d2.x, d2.y, ds.x, ds.y};
+    });
 }
 
 // per-lane parameters: params[sub][s][gb][gp][fb][lane][8] = {b00, b01, b10, b11, base, 0, 0, 0}
