@@ -181,6 +181,13 @@ def main():
         roofline = dict(bound="mfma", kernel=dominant, achieved=round(ach, 2), peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / FP32_PEAK_TFLOPS, 4), traffic=traffic, traffic_unit="GB per launch (2*FETCH_SIZE+WRITE_SIZE)", kernels=kern,
                         whole_step_tflops=round(32.0 * unit_px * args.steps / elapsed / 1e12, 2))
+        # the BASELINE metric also asks for the HBM view: compulsory bytes of one fwd+bwd step (SURVEY.md 8d:
+        # e*N*H*W*(3S+2F) + 7*4*S*G*F) over the step time, against the 8 TB/s roof -- ~1 %, the operator is compute bound
+        e = 2 if args.io == "bf16" else 4
+        step_bytes = float(e) * N * H * W * (3 * S + 2 * F) + 28.0 * S * G * F
+        gbps = step_bytes * args.steps * world / elapsed / 1e9
+        roofline["hbm_algorithmic"] = dict(bytes_per_step=step_bytes, achieved_GBps=round(gbps / world, 1), peak_GBps=8000.0,
+                                           frac=round(gbps / world / 8000.0, 4))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
