@@ -29,7 +29,8 @@
  *   dau_conv_unit_table               perpare_weights_and_offsets (dau_conv_forward_core.hpp:1858-2215)
  *   dau_conv_last_error               DAUException::what (include/dau_conv/util/common.hpp:40-66)
  *
- * Tensor layouts (identical to the reference): activations NCHW contiguous float32;
+ * Tensor layouts (identical to the reference): activations NCHW contiguous float32 (or,
+ * with DAU_FLAG_IO_BF16, bfloat16 storage of x, y, dy, dx -- arithmetic stays fp32);
  * parameters and their gradients [1,S,G,F] contiguous float32 (f fastest); sigma is a
  * full [1,S,G,F] tensor whose element 0 is used (base_dau_conv_layer.hpp:266-275).
  *
