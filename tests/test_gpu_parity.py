@@ -272,3 +272,26 @@ def test_stacked_gather_variants(shape, monkeypatch):
     want = orc.backward(x, dy, w, mu1, mu2, 0.5)
     for t, key in zip(got, ("dx", "dw", "dmu1", "dmu2", "dsigma")):
         assert_parity(t.cpu().numpy(), want[key], key)
+
+
+def test_calls_on_a_side_stream():
+    """Every kernel is launched on the stream handed to the ABI (no default-stream work, no device-wide sync)."""
+    from dau_conv import _capi
+    rs = np.random.RandomState(21)
+    N, S, F, G, H, W = 4, 6, 32, 4, 28, 28
+    x = rs.rand(N, S, H, W).astype(np.float32); dy = rs.randn(N, F, H, W).astype(np.float32)
+    w = (rs.randn(1, S, G, F) * 0.1).astype(np.float32)
+    mu1 = rs.uniform(-3, 3, (1, S, G, F)).astype(np.float32); mu2 = rs.uniform(-3, 3, (1, S, G, F)).astype(np.float32)
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        xd, dyd, wd, m1d, m2d = (_dev(a) for a in (x, dy, w, mu1, mu2))
+        sigma = torch.full((1, S, G, F), 0.5, device="cuda")
+        y = plan.forward(xd, wd, m1d, m2d, sigma)
+        got = plan.backward(xd, dyd, wd, m1d, m2d, sigma)
+        plan.check_status()
+    side.synchronize()
+    assert_parity(y.cpu().numpy(), orc.forward(x, w, mu1, mu2, 0.5), "y")
+    want = orc.backward(x, dy, w, mu1, mu2, 0.5)
+    for t, key in zip(got, ("dx", "dw", "dmu1", "dmu2", "dsigma")):
+        assert_parity(t.cpu().numpy(), want[key], key)
