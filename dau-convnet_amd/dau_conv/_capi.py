@@ -111,8 +111,14 @@ def _req(t, name, shape=None, dtype=torch.float32):
     return t
 
 
+# One grow-only workspace per (device, stream), shared by every plan: the layers of a network run one after the other on
+# a stream, so they can reuse the same scratch memory (a north-star sized layer needs 3 GB for its backward pass).  The
+# status word at the head of the workspace is read back by check_status() right after the call that wrote it.
+_SHARED_WS = {}
+
+
 class Plan(object):
-    """Owns one dau_conv_plan plus lazily allocated workspaces (one per pass)."""
+    """Owns one dau_conv_plan; scratch memory comes from the per-stream shared workspace."""
 
     def __init__(self, N, S, F, G, H, W, max_kernel_size=9, number_units_ignore=0, flags=FLAG_USE_INTERPOLATION,
                  algo=ALGO_AUTO, sigma_hint=0.5, mu_learning_rate_factor=1.0):
@@ -139,11 +145,13 @@ class Plan(object):
         return n.value
 
     def _workspace(self, which, device):
-        key = (which, device)
-        ws = self._ws.get(key)
-        if ws is None:
-            ws = torch.empty(self.workspace_bytes(which), dtype=torch.uint8, device=device)
-            self._ws[key] = ws
+        need = self._ws.get(which)
+        if need is None:
+            need = self._ws[which] = self.workspace_bytes(which)
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        ws = _SHARED_WS.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _SHARED_WS[key] = torch.empty(need, dtype=torch.uint8, device=device)
         return ws
 
     def forward(self, x, w, mu1, mu2, sigma):
