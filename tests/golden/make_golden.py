@@ -53,6 +53,12 @@ CASES = [
     dict(name="forbid_positive", N=1, S=2, F=4, H=9, W=20, G=2, m=3.0, single_dim_kernel=True,
          forbid_positive=True, mu2_zero=True),
     dict(name="config0_quick", N=2, S=16, F=32, H=32, W=32, G=2, m=3.0),
+    # added later (appended, so that the random stream of the cases above is unchanged): unit counts and map sizes that
+    # exercise the unit passes, stacked planes and 7-row regions of the tiled kernels
+    dict(name="g6_28x28", N=3, S=4, F=8, H=28, W=28, G=6, m=3.0),
+    dict(name="g8_14x14", N=5, S=3, F=8, H=14, W=14, G=8, m=3.0),
+    dict(name="g3_7x7_k17", N=4, S=4, F=8, H=7, W=7, G=3, m=6.0),
+    dict(name="g5_20x100", N=1, S=2, F=4, H=20, W=100, G=5, m=3.0),
 ]
 
 
