@@ -71,6 +71,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the operator)")
+    # DAU_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices,
+    # the all-reduce goes through gloo); the measured configuration is always nccl = RCCL, one rank per GPU
+    backend = os.environ.get("DAU_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # under torch.distributed.run (RANK set) the exchange path is used even for one rank, so that a 1-GPU box can
@@ -85,7 +90,10 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -207,7 +215,8 @@ def main():
         out = dict(metric="DAU fwd+bwd GSamples/s (N*H*W/s)", value=round(value, 6), unit="GSamples/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload=wl["label"] + (" [bf16 activations in HBM]" if args.io == "bf16" else ""),
+                   config=dict(workload=wl["label"] + (" [bf16 activations in HBM]" if args.io == "bf16" else "") +
+                               ("" if backend == "nccl" else " [REHEARSAL: %s backend, ranks share GPUs]" % backend),
                                global_batch=N * world, parallelism="dp%d" % world,
                                algo_forward=plan.info["algo_forward"], algo_backward=plan.info["algo_backward"]),
                    roofline=roofline, cpu_baseline=cpu)
