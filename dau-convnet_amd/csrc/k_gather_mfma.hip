@@ -170,7 +170,9 @@ struct BlurPackArgs {
     int rows, pitch, cols, strip_cols;
     size_t plane_floats;
     int ppb;                    // planes per workgroup (small planes: every group of 8/ppb waves blurs its own plane)
-    int planes;                 // (image pair, patch, channel) planes in total
+    int bands, band_rows;       // big planes: a workgroup writes band_rows staged rows of its plane (less LDS, more
+                                // workgroups per CU to hide the memory latency of this HBM-bound kernel)
+    int planes;                 // (image pair, patch, channel, band) work items in total
     unsigned lds_plane_floats;  // LDS floats per plane
 };
 
@@ -185,13 +187,16 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
     int pid = blockIdx.x * a.ppb + sub;
     const bool active = pid < a.planes;           // the last workgroup may have idle wave groups (they still reach the barriers)
     if (!active) pid = a.planes - 1;
+    const int band = pid % a.bands; pid /= a.bands;
+    const int row0 = band * a.band_rows, row1 = row0 + a.band_rows < a.rows ? row0 + a.band_rows : a.rows;   // staged rows of this band
     const int c = pid % C;
     const int npp = pid / C;                       // (image pair, patch)
     const int npatch = a.npx * a.npy;
     const int np = npp / npatch, patch = npp % npatch;
     const int wy0 = (patch / a.npx) * a.ph - R + a.cy, wx0 = (patch % a.npx) * a.pw - R + a.cx;   // image coordinates of staged (0, 0)
     // the part of the window that lies inside the image
-    const int ya0 = wy0 > 0 ? wy0 : 0, ya1 = wy0 + a.rows < H ? wy0 + a.rows : H;
+    const int ya0 = wy0 + row0 > 0 ? wy0 + row0 : 0;
+    const int ya1r = wy0 + row1 < H ? wy0 + row1 : H, ya1 = ya1r > ya0 ? ya1r : ya0;
     const int xa0 = wx0 > 0 ? wx0 : 0, xa1 = wx0 + a.cols < W ? wx0 + a.cols : W;
     const int kr = (k - 1) / 2;
     const int bw = xa1 - xa0;
@@ -240,7 +245,8 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
     __syncthreads();
     f2* out = reinterpret_cast<f2*>(a.staged + ((size_t)npp * C + c) * a.plane_floats);
     f2* strip = out + (size_t)a.rows * a.pitch;
-    for_each(active ? a.rows : 0, a.pitch, [&](int row, int col) {
+    for_each(active ? row1 - row0 : 0, a.pitch, [&](int brow, int col) {
+        const int row = row0 + brow;
         const int iy = wy0 + row, ix = wx0 + col;
         f2 acc = {0.0f, 0.0f};
         if (iy >= ya0 && iy < ya1 && ix >= xa0 && ix < xa1) {
@@ -607,9 +613,10 @@ void launch_variant(hipStream_t st, const GatherArgs& a, int grid, size_t lds) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T::kThreads), lds, st, a);
 }
 
-// largest window any patch needs: raw [lh][lw] + horizontally filtered [lh][bw]
-size_t blur_pack_lds_bytes(const Geometry& g, int k) {
-    const size_t wh = g.rows < g.H ? g.rows : g.H, ww = g.cols < g.W ? g.cols : g.W;
+// largest window any patch (band of band_rows staged rows) needs: raw [lh][lw] + horizontally filtered [lh][bw]
+size_t blur_pack_lds_bytes(const Geometry& g, int k, int band_rows = 0) {
+    const int rows = band_rows > 0 && band_rows < g.rows ? band_rows : g.rows;
+    const size_t wh = rows < g.H ? rows : g.H, ww = g.cols < g.W ? g.cols : g.W;
     return ((wh + k - 1) * (ww + k - 1) + (wh + k - 1) * ww) * 8;
 }
 
@@ -652,7 +659,11 @@ void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in,
     const Geometry g = make_geometry(c.H, c.W, c.R, c.G, c.N, c.Cout, c.variant);
     char* staged = static_cast<char*>(workspace);
     char* packed = staged + round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256);
-    const size_t blur_lds = blur_pack_lds_bytes(g, c.blur_k);
+    // planes that need more than ~40 KiB of LDS are staged in two (or more) row bands
+    int bands = 1;
+    while (bands < 8 && blur_pack_lds_bytes(g, c.blur_k, (g.rows + bands - 1) / bands) > 40 * 1024) ++bands;
+    const int band_rows = (g.rows + bands - 1) / bands;
+    const size_t blur_lds = blur_pack_lds_bytes(g, c.blur_k, band_rows);
     // sigma = 0.5 (the reference's default) gives a 7-tap prefilter; other supports take the generic instantiation
     auto kern = c.blur_k == 7 ? blur_pack_kernel<7> : c.blur_k == 5 ? blur_pack_kernel<5> : c.blur_k == 9 ? blur_pack_kernel<9> : blur_pack_kernel<0>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -669,7 +680,9 @@ void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in,
     const int elems = g.rows * g.pitch;
     b.ppb = elems >= 4096 ? 1 : elems >= 2048 ? 2 : elems >= 1024 ? 4 : 8;
     while (b.ppb > 1 && b.ppb * blur_lds > 64 * 1024) b.ppb /= 2;
-    b.planes = c.NP * c.patches * c.Cin;
+    b.bands = bands; b.band_rows = band_rows;
+    if (bands > 1) b.ppb = 1;
+    b.planes = c.NP * c.patches * c.Cin * bands;
     b.lds_plane_floats = (unsigned)(blur_lds / 4);
     hipLaunchKernelGGL(kern, dim3((b.planes + b.ppb - 1) / b.ppb), dim3(512), b.ppb * blur_lds, st, b);
     const int nfb = (c.Cout + g.fb - 1) / g.fb;
