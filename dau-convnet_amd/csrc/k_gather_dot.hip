@@ -139,34 +139,43 @@ DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one
 // ------------------------------------------------------------------------------------------------
 // dy[N,F,H,W] -> EP[NP][nfb][EY][EX][32][2]; padded coordinate Y = y + R + 1, zero elsewhere; the
 // unit_testing edge rule (last column / row of the error dropped) is applied here.
-// One workgroup per (pair, channel block, padded row): 64 coalesced row reads -> LDS -> one contiguous
-// EX*256 B write (a transpose from channel-major to position-major).  HBM bound.
+// One workgroup per (pair, channel block, padded row, chunk of XC padded columns): 64 coalesced row reads -> LDS ->
+// one contiguous write of up to XC*256 B (a transpose from channel-major to position-major).  HBM bound.
+constexpr int kPackErrorChunk = 512;   // padded columns per workgroup (LDS: 64 rows of up to 513 floats)
+
 __global__ void __launch_bounds__(256) pack_error_kernel(const float* __restrict__ dy, int N, int F, int H, int W, int R,
                                                          int EX, int EY, int nfb, int drop_col, int drop_row, int bf16,
                                                          float* __restrict__ ep) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // [64 = 32 f x 2 images][W | 1]
-    const int Y = blockIdx.x % EY;
-    const int fb = (blockIdx.x / EY) % nfb;
-    const int np = blockIdx.x / (EY * nfb);
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [64 = 32 f x 2 images][chunk width | 1]
+    const int nxc = (EX + kPackErrorChunk - 1) / kPackErrorChunk;
+    int t0 = blockIdx.x;
+    const int xc = t0 % nxc; t0 /= nxc;
+    const int Y = t0 % EY; t0 /= EY;
+    const int fb = t0 % nfb;
+    const int np = t0 / nfb;
     const int y = Y - (R + 1);
-    const int wp = W | 1;                                   // odd pitch: conflict-free transposed reads
+    const int X0 = xc * kPackErrorChunk, X1 = X0 + kPackErrorChunk < EX ? X0 + kPackErrorChunk : EX;   // padded columns
+    // image columns of this chunk: x = X - (R + 1), clipped to the image
+    const int xa0 = X0 - (R + 1) > 0 ? X0 - (R + 1) : 0, xa1 = X1 - (R + 1) < W ? X1 - (R + 1) : W;
+    const int cw = xa1 > xa0 ? xa1 - xa0 : 0;
+    const int wp = (cw > 0 ? cw : 1) | 1;                   // odd pitch: conflict-free transposed reads
     const bool rowin = y >= 0 && y < H && !(drop_row && y == H - 1);
-    if (rowin) {
+    if (rowin && cw > 0) {
         // flat over (r = fl*2 + image, x): narrow maps keep all lanes busy (a 7-pixel row per wave instruction did not)
-        for (int t = threadIdx.x; t < 64 * W; t += blockDim.x) {
-            const int r = t / W, x = t - r * W;
+        for (int t = threadIdx.x; t < 64 * cw; t += blockDim.x) {
+            const int r = t / cw, x = t - r * cw;
             const int f = fb * kDF + (r >> 1), n = 2 * np + (r & 1);
             const bool ok = f < F && n < N;
-            const long src = (((long)(ok ? n : 0) * F + (ok ? f : 0)) * H + y) * W;
+            const long src = (((long)(ok ? n : 0) * F + (ok ? f : 0)) * H + y) * W + xa0;
             lds[r * wp + x] = ok ? load_act(dy, src + x, bf16 != 0) : 0.0f;
         }
     }
     __syncthreads();
-    float* out = ep + ((((size_t)np * nfb + fb) * EY + Y) * EX) * (kDF * 2);
+    float* out = ep + ((((size_t)np * nfb + fb) * EY + Y) * EX + X0) * (kDF * 2);
     const int wlim = drop_col ? W - 1 : W;
-    for (int t = threadIdx.x; t < EX * 64; t += blockDim.x) {
-        const int X = t >> 6, r = t & 63, x = X - (R + 1);
-        out[t] = (rowin && x >= 0 && x < wlim) ? lds[r * wp + x] : 0.0f;
+    for (int t = threadIdx.x; t < (X1 - X0) * 64; t += blockDim.x) {
+        const int X = X0 + (t >> 6), r = t & 63, x = X - (R + 1);
+        out[t] = (rowin && x >= xa0 && x < xa1 && x < wlim) ? lds[r * wp + (x - xa0)] : 0.0f;
     }
 }
 
@@ -722,7 +731,6 @@ bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, TiledDot
     const bool one_tile = getenv("DAU_DOT_NBUF") && atoi(getenv("DAU_DOT_NBUF")) == 1;
     const DotGeometry g = make_dot_geometry(sh, R, as1, one_tile);
     if (g.tile_bytes > 160 * 1024) return false;
-    if ((size_t)64 * (sh.W | 1) * 4 > 160 * 1024) return false;   // pack_error_kernel transposes whole rows through LDS
     // immediates of the unrolled column walk must fit 16 bits
     if ((size_t)g.epitch * kDF * 8 + (kRW + 1) * kDF * 8 > 65535) return false;
     {
@@ -750,9 +758,11 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
     const Shape& s = c.sh;
     const int s_pad = g.s_pad;
     {
-        const size_t lds = (size_t)64 * (s.W | 1) * 4;
+        const int cwmax = s.W < kPackErrorChunk ? s.W : kPackErrorChunk;
+        const size_t lds = (size_t)64 * (cwmax | 1) * 4;
+        const int nxc = (g.EX + kPackErrorChunk - 1) / kPackErrorChunk;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pack_error_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(pack_error_kernel, dim3(c.NP * g.nfb * g.EY), dim3(256), lds, st, dy, s.N, s.F, s.H, s.W, c.R, g.EX,
+        hipLaunchKernelGGL(pack_error_kernel, dim3(c.NP * g.nfb * g.EY * nxc), dim3(256), lds, st, dy, s.N, s.F, s.H, s.W, c.R, g.EX,
                            g.EY, g.nfb, drop_col, drop_row, c.bf16 ? 1 : 0, reinterpret_cast<float*>(ws + l.ep_off));
     }
     {

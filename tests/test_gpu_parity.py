@@ -72,7 +72,7 @@ def test_tiled_kernels_are_selected_for_benchmark_shapes():
         assert info["algo_forward"] == _capi.ALGO_TILED, (H, W, k, info)
     # gather-dot: any image size, any unit count, kernels 9 and 17
     for (H, W, k, G) in ((56, 56, 9, 4), (27, 27, 9, 4), (65, 8, 9, 2), (32, 32, 17, 6), (56, 56, 17, 8), (100, 90, 9, 1),
-                         (64, 64, 33, 4), (64, 64, 65, 9), (512, 512, 33, 9)):
+                         (64, 64, 33, 4), (64, 64, 65, 9), (512, 512, 33, 9), (16, 2000, 9, 2)):
         info = _capi.Plan(2, 4, 8, G, H, W, max_kernel_size=k).info
         assert info["algo_backward"] == _capi.ALGO_TILED, (H, W, k, G, info)
 
@@ -189,6 +189,9 @@ def test_error_convention():
     # offset windows of the gather-dot for kernels 33 and 65 with offsets over the whole range
     dict(N=2, W=40, H=40, S=5, F=33, G=3, k=33, m=16),
     dict(N=1, W=48, H=40, S=3, F=8, G=2, k=65, m=32),
+    # very wide maps: the error rows are transposed in chunks of 512 padded columns
+    dict(N=1, W=700, H=9, S=2, F=3, G=2, k=9, m=3),
+    dict(N=2, W=1100, H=8, S=1, F=2, G=1, k=17, m=7),
     # degenerate sizes: one pixel, one channel, one unit; a 2x3 image
     dict(N=1, W=1, H=1, S=1, F=1, G=1, k=9, m=3),
     dict(N=3, W=3, H=2, S=2, F=3, G=2, k=9, m=3),
