@@ -620,6 +620,13 @@ size_t blur_pack_lds_bytes(const Geometry& g, int k, int band_rows = 0) {
     return ((wh + k - 1) * (ww + k - 1) + (wh + k - 1) * ww) * 8;
 }
 
+// planes that need more than ~40 KiB of LDS are staged in two (or more) row bands
+int blur_pack_bands(const Geometry& g, int k) {
+    int bands = 1;
+    while (bands < 8 && blur_pack_lds_bytes(g, k, (g.rows + bands - 1) / bands) > 40 * 1024) ++bands;
+    return bands;
+}
+
 size_t lds_bytes(const TiledConfig& c, const Geometry& g) {
     const size_t main_b = 2 * g.sk * g.plane_bytes + 2 * ut_stride_bytes(c.G, g.fb);
     const size_t zpitch = g.pw + 2;
@@ -641,7 +648,7 @@ bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R
     c.bf16 = bf16 ? 1 : 0;
     if (lds_bytes(c, g) > 160 * 1024) return false;
     // blur_pack keeps both raw planes (+ blur halo) and the horizontally filtered rows in LDS
-    if (blur_pack_lds_bytes(g, blur_k) > 150 * 1024) return false;
+    if (blur_pack_lds_bytes(g, blur_k, (g.rows + blur_pack_bands(g, blur_k) - 1) / blur_pack_bands(g, blur_k)) > 150 * 1024) return false;
     *cfg = c;
     return true;
 }
@@ -659,9 +666,7 @@ void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in,
     const Geometry g = make_geometry(c.H, c.W, c.R, c.G, c.N, c.Cout, c.variant);
     char* staged = static_cast<char*>(workspace);
     char* packed = staged + round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256);
-    // planes that need more than ~40 KiB of LDS are staged in two (or more) row bands
-    int bands = 1;
-    while (bands < 8 && blur_pack_lds_bytes(g, c.blur_k, (g.rows + bands - 1) / bands) > 40 * 1024) ++bands;
+    const int bands = blur_pack_bands(g, c.blur_k);
     const int band_rows = (g.rows + bands - 1) / bands;
     const size_t blur_lds = blur_pack_lds_bytes(g, c.blur_k, band_rows);
     // sigma = 0.5 (the reference's default) gives a 7-tap prefilter; other supports take the generic instantiation

@@ -298,3 +298,24 @@ def test_calls_on_a_side_stream():
     want = orc.backward(x, dy, w, mu1, mu2, 0.5)
     for t, key in zip(got, ("dx", "dw", "dmu1", "dmu2", "dsigma")):
         assert_parity(t.cpu().numpy(), want[key], key)
+
+
+def test_widest_prefilter_stays_on_the_tiled_kernels():
+    """sigma = 1.6 gives the 17-tap prefilter (the largest supported, convolve.cu:40,245); staging bands keep it in LDS."""
+    from dau_conv import _capi
+    rs = np.random.RandomState(9)
+    N, S, F, G, H, W, k, sg = 2, 3, 8, 2, 60, 70, 17, 1.6
+    x = rs.rand(N, S, H, W).astype(np.float32); dy = rs.randn(N, F, H, W).astype(np.float32)
+    w = (rs.randn(1, S, G, F) * 0.1).astype(np.float32)
+    mu1 = rs.uniform(-7, 7, (1, S, G, F)).astype(np.float32); mu2 = rs.uniform(-7, 7, (1, S, G, F)).astype(np.float32)
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, sigma_hint=sg)
+    assert plan.info["blur_support"] == 17
+    assert plan.info["algo_forward"] == _capi.ALGO_TILED and plan.info["algo_backward"] == _capi.ALGO_TILED
+    sigma = torch.full((1, S, G, F), sg, device="cuda")
+    y = plan.forward(_dev(x), _dev(w), _dev(mu1), _dev(mu2), sigma)
+    got = plan.backward(_dev(x), _dev(dy), _dev(w), _dev(mu1), _dev(mu2), sigma)
+    plan.check_status()
+    assert_parity(y.cpu().numpy(), orc.forward(x, w, mu1, mu2, sg), "y")
+    want = orc.backward(x, dy, w, mu1, mu2, sg)
+    for t, key in zip(got, ("dx", "dw", "dmu1", "dmu2", "dsigma")):
+        assert_parity(t.cpu().numpy(), want[key], key)
