@@ -3,6 +3,8 @@ oracle.  The reference's tests walk a fixed matrix (dau_conv_test.py:418-501); t
 between: ragged image sizes that exercise the patch / region / window decompositions of the tiled kernels, odd channel
 counts (partial channel blocks), every flag, ignored units, and prefilter supports other than the 7 taps of sigma 0.5.
 Tolerance: 1e-4 relative (util.assert_parity)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -38,7 +40,8 @@ def _config(seed):
                 m=float(rs.uniform(0.5, k // 2)), seed=seed)
 
 
-@pytest.mark.parametrize("seed", range(120))
+# DAU_FUZZ_SEEDS=<n> widens the sweep for a soak run (default 120)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DAU_FUZZ_SEEDS", "120"))))
 def test_random_configuration(seed):
     from dau_conv import _capi
     c = _config(seed)
