@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
 """Benchmark of the DAU forward+backward hot path (BASELINE.json metric: GSamples/s = N*H*W / (t_fwd+t_bwd)).
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+For N > 1 this starts N ranks itself (one per GPU, `python -m torch.distributed.run ... bench.py`), relays rank 0's one
+JSON line and exits with the ranks' return code; started under torch.distributed.run (RANK set) it is one of those ranks.
 
 One "step" = dau_conv_forward + dau_conv_backward (dx, dw, dmu1, dmu2, dsigma) over one synthetic batch that is
-already resident in HBM, plus -- for N>1 -- the RCCL all-reduce of the four parameter-gradient tensors.  The batch
-is sharded over ranks (weak scaling: 128 images per GPU).  Rank 0 prints ONE JSON line.
+already resident in HBM.  With more than one rank the batch is sharded (weak scaling: the per-GPU batch is fixed), the
+raw parameter-gradient sums [4,S,G,F] are all-reduced over RCCL/xGMI under the dx pass and finalized after the
+exchange.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline      dominant kernel's ALGORITHMIC FLOPs per launch / its average launch time, measured live with HIP
-                events on the launch stream (dau_conv_profile_begin/_end).  The operator is compute bound (1640 FLOP/B
-                at this shape), so the roof is the fp32 matrix/vector peak of 157.3 TFLOP/s.
+  roofline      dominant kernel's ALGORITHMIC FLOPs per pass / its average time per pass, measured live with HIP
+                events on the launch stream (dau_conv_profile_begin/_end; a pass over large offsets takes several
+                window launches, whose times add).  The operator is compute bound (1640 FLOP/B at the north-star shape,
+                SURVEY.md 8d), so the roof is the fp32 matrix/vector peak of 157.3 TFLOP/s.
   cpu_baseline  the CPU oracle (oracle/dau_oracle.c, OpenMP) timed on this box's host cores on a small slice of the
                 same workload.  A reported baseline, not a target.
+  layer         the same step through the drop-in layer (dau_conv.DAUConv2d + autograd, default check_offsets), so that
+                the binding's host work is visible next to the ABI-level number.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,10 +35,6 @@ for _p in (ROOT, os.path.join(ROOT, "dau-convnet_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 WORKLOADS = {
     # north star of BASELINE.json: N=128 C=256->256 HW=56, 4-unit DAU, fp32, max_kernel_size 9, mu ~ U(-3,3)
     "ns": dict(N=128, S=256, F=256, H=56, W=56, G=4, k=9, m=3.0,
@@ -36,24 +42,28 @@ WORKLOADS = {
     # AlexNet-DAU conv2 shape (configs[1])
     "c1": dict(N=64, S=96, F=256, H=27, W=27, G=4, k=9, m=3.0,
                label="AlexNet-DAU conv2 N=64/GPU C=96->256 HW=27 G=4 k=9 fp32 fwd+bwd"),
-    # configs[2] at fp32 (bf16 is not implemented): six units per channel
+    # configs[2]: six units per channel; BASELINE names bf16 activations: run with --io bf16
     "c2": dict(N=128, S=256, F=256, H=56, W=56, G=6, k=9, m=3.0,
-               label="ResNet-50-DAU layer N=128/GPU C=256->256 HW=56 G=6 k=9 fp32 fwd+bwd"),
+               label="ResNet-50-DAU layer N=128/GPU C=256->256 HW=56 G=6 k=9 fwd+bwd"),
     # configs[3]: per-GPU share of the N=1024 batch-sharded step
     "c3": dict(N=128, S=512, F=512, H=28, W=28, G=4, k=9, m=3.0,
                label="batch-sharded step N=128/GPU C=512->512 HW=28 G=4 k=9 fp32 fwd+bwd"),
-    # configs[4]: segmentation-scale maps, nine units, offsets up to +-17 => offset bucket 32 (max_kernel_size 65)
-    "c4": dict(N=16, S=256, F=256, H=512, W=512, G=9, k=65, m=17.0,
-               label="seg-scale N=16/GPU C=256->256 HW=512 G=9 k=65 mu~U(-17,17) fp32 fwd+bwd"),
-    # the same maps with offsets within +-16 (bucket 16, max_kernel_size 33)
-    "c4k33": dict(N=16, S=256, F=256, H=512, W=512, G=9, k=33, m=15.0,
-               label="seg-scale N=16/GPU C=256->256 HW=512 G=9 k=33 mu~U(-15,15) fp32 fwd+bwd"),
+    # configs[4]: segmentation-scale maps, nine live units (ten stored, one ignored, as the layer pads
+    # odd unit counts), offsets up to +-17 under max_kernel_size 65
+    "c4": dict(N=16, S=256, F=256, H=512, W=512, G=10, ignore=1, k=65, m=17.0,
+               label="seg-scale N=16/GPU C=256->256 HW=512 G=9(+1 ignored) k=65 mu~U(-17,17) fp32 fwd+bwd"),
+    # the same maps with offsets within +-16 (max_kernel_size 33)
+    "c4k33": dict(N=16, S=256, F=256, H=512, W=512, G=10, ignore=1, k=33, m=15.0,
+               label="seg-scale N=16/GPU C=256->256 HW=512 G=9(+1 ignored) k=33 mu~U(-15,15) fp32 fwd+bwd"),
+    # the reference's "big kernel, small offsets" case at the north-star size (dau_conv_test.py:433,436)
+    "nsk65": dict(N=128, S=256, F=256, H=56, W=56, G=4, k=65, m=3.0,
+               label="north-star shape under max_kernel_size 65 with mu~U(-3,3) (per-call bucket selection)"),
     "small": dict(N=8, S=32, F=32, H=56, W=56, G=4, k=9, m=3.0, label="smoke-size N=8 C=32->32 HW=56 G=4"),
 }
 FP32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -64,11 +74,89 @@ def main():
                     help="storage type of x, y, dy, dx (BASELINE config 2 names bf16); arithmetic is fp32 either way")
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 direct, 2 tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-layer", action="store_true", help="skip the layer-level (DAUConv2d + autograd) timing")
+    ap.add_argument("--check", type=int, default=0, metavar="IMAGES",
+                    help="parity gate before timing: y and dx of the first IMAGES images against the CPU oracle")
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """--gpus N > 1 outside torch.distributed.run: start the N ranks (no GPU call has happened in this process), relay
+    rank 0's JSON line, return the ranks' exit code."""
+    import torch  # device_count() does not initialise the GPU
+    backend = os.environ.get("DAU_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible (one rank per GPU over RCCL); "
+                         "DAU_BENCH_BACKEND=gloo rehearses the multi-rank path on fewer GPUs\n" % (args.gpus, have))
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.strip()
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        elif out:
+            sys.stderr.write(out + "\n")
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        sys.stderr.write("bench.py: the ranks finished without printing a result line\n")
+        rc = 3
+    if line is not None and rc == 0:
+        print(line)
+    return rc
+
+
+def lib_fingerprint():
+    path = os.path.join(ROOT, "dau-convnet_amd", "dau_conv", "libdau_conv_hip.so")
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(workload_key, io, dominant):
+    """HBM bytes per pass of the dominant kernel from the committed rocprofv3 --pmc passes of THIS command
+    (tools/pmc_traffic.sh writes profiles/r2_pmc_traffic.json: counters cannot be read from inside the process).  Only
+    used when that file was taken for this workload with this very build of the library; otherwise null + the reason."""
+    path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+    try:
+        pmc = json.load(open(path))
+    except Exception:
+        return None, "no PMC pass committed for this build (profiles/r2_pmc_traffic.json missing)"
+    run = pmc.get("runs", {}).get("%s/%s" % (workload_key, io))
+    if run is None:
+        return None, "no PMC pass committed for workload %s/%s" % (workload_key, io)
+    if run.get("lib_sha256_16") != lib_fingerprint():
+        return None, "committed PMC pass is from another build of the library (stale)"
+    key = {"gather_dot": "dau::gather_dot_kernel", "gather_sum_fwd": "dau::gather_mfma_kernel",
+           "gather_sum_dx": "dau::gather_mfma_kernel"}.get(dominant, "")
+    hits = [v["hbm_bytes_per_pass"] for k, v in run["kernels"].items() if key and k.startswith(key)]
+    if not hits:
+        return None, "dominant kernel not in the committed PMC pass"
+    return round(hits[0] / 1e9, 3), "profiles/r2_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, separate passes)"
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (start it as `python bench.py --gpus N`, or under "
+                         "torch.distributed.run with --nproc-per-node equal to --gpus)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the operator)")
     # DAU_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks share devices,
@@ -102,12 +190,16 @@ def main():
 
     from dau_conv import _capi
 
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    wl_key = args.workload
     if args.shape:
         v = args.shape.split(",")
         wl = dict(N=int(v[0]), S=int(v[1]), F=int(v[2]), H=int(v[3]), W=int(v[4]), G=int(v[5]), k=int(v[6]),
                   m=float(v[7]) if len(v) > 7 else 3.0, label="ad-hoc " + args.shape)
+        wl_key = "adhoc:" + args.shape
     N, S, F, H, W, G, k, m = (wl[q] for q in ("N", "S", "F", "H", "W", "G", "k", "m"))
+    ignore = int(wl.get("ignore", 0))
+    G_live = G - ignore
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     pgen = torch.Generator(device=dev)
@@ -116,6 +208,8 @@ def main():
     x = torch.rand((N, S, H, W), device=dev, generator=gen)
     dy = torch.randn((N, F, H, W), device=dev, generator=gen)
     w = torch.randn((1, S, G, F), device=dev, generator=pgen) * 0.1
+    if ignore:
+        w[:, :, G - ignore:, :] = 0.0          # ZeroNLast, as the layer initialises its padded unit (dau_conv.py:317-329)
     lim = k // 2 - 0.01
     mu1 = ((torch.rand((1, S, G, F), device=dev, generator=pgen) * 2 - 1) * m).clamp_(-lim, lim)
     mu2 = ((torch.rand((1, S, G, F), device=dev, generator=pgen) * 2 - 1) * m).clamp_(-lim, lim)
@@ -123,7 +217,7 @@ def main():
 
     if args.io == "bf16":
         x, dy = x.to(torch.bfloat16), dy.to(torch.bfloat16)
-    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, algo=args.algo,
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, number_units_ignore=ignore, algo=args.algo,
                       flags=_capi.FLAG_USE_INTERPOLATION | (_capi.FLAG_IO_BF16 if args.io == "bf16" else 0),
                       sigma_hint=0.5, mu_learning_rate_factor=1.0)
     from dau_conv.distributed import OverlappedBackward
@@ -132,9 +226,11 @@ def main():
     def step():
         y = plan.forward(x, w, mu1, mu2, sigma)
         if use_dist:
-            # batch-sharded data parallelism: one all-reduce of [dw|dmu1|dmu2|dsigma] over RCCL/xGMI, issued after the
-            # gather-dot pass and hidden under the dx pass
-            dx = exchange.run(lambda need: plan.backward(x, dy, w, mu1, mu2, sigma, need_mask=need))
+            # batch-sharded data parallelism: one all-reduce of the raw sums [4,S,G,F] over RCCL/xGMI, issued after the
+            # gather-dot pass and hidden under the dx pass; the elementwise tail runs on the reduced sums
+            dx = exchange.run(lambda out: plan.backward_param_sums(x, dy, mu1, mu2, sigma, out=out),
+                              lambda: plan.backward(x, dy, w, mu1, mu2, sigma, need_mask=_capi.NEED_DX)[0],
+                              lambda sums: plan.finalize_param_grads(sums, w))
             exchange.wait()
         else:
             dx = plan.backward(x, dy, w, mu1, mu2, sigma)[0]
@@ -144,6 +240,26 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    parity = None
+    if args.check > 0 and rank == 0:
+        from oracle import dau_oracle as orc
+        nchk = min(args.check, N)
+        y, dx = step()
+        torch.cuda.synchronize()
+        xs, dys = x[:nchk].float().cpu().numpy(), dy[:nchk].float().cpu().numpy()
+        wn, m1n, m2n = w.cpu().numpy(), mu1.cpu().numpy(), mu2.cpu().numpy()
+        want_y = orc.forward(xs, wn, m1n, m2n, 0.5, ignore=ignore)
+        want_dx = orc.backward(xs, dys, wn, m1n, m2n, 0.5, ignore=ignore, need=("dx",))["dx"]
+        rel, floor = (2e-2, 4e-3) if args.io == "bf16" else (1e-4, 1e-6)
+
+        def viol(got, want):
+            got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+            return float((np.abs(got - want) - (rel * np.abs(want) + floor * np.abs(want).max())).max())
+        vy, vdx = viol(y[:nchk].float().cpu().numpy(), want_y), viol(dx[:nchk].float().cpu().numpy(), want_dx)
+        parity = dict(images=nchk, y_violation=vy, dx_violation=vdx, ok=bool(vy <= 0 and vdx <= 0), rel=rel, floor=floor)
+        if not parity["ok"]:
+            raise SystemExit("bench.py --check: the HIP path differs from the oracle: %s" % parity)
 
     for _ in range(args.warmup):
         step()
@@ -163,31 +279,23 @@ def main():
 
     samples = float(N) * world * H * W * args.steps
     value = samples / elapsed / 1e9
-    # algorithmic FLOPs per launch: 4 MAC per (n,px,s,g,f) for each gather-sum, 8 MAC for gather-dot
-    unit_px = float(G) * N * H * W * S * F
+    # algorithmic FLOPs per pass: 4 MAC per (n,px,s,g,f) for each gather-sum, 8 MAC for gather-dot,
+    # over the live units
+    unit_px = float(G_live) * N * H * W * S * F
     flops = {"gather_sum_fwd": 8.0 * unit_px, "gather_sum_dx": 8.0 * unit_px, "gather_dot": 16.0 * unit_px}
     kern = {}
-    for name, (ms, launches) in prof.items():
-        if launches:
-            avg = ms / launches
-            kern[name] = dict(avg_ms=round(avg, 4), launches=launches, tflops=round(flops[name] / (avg * 1e-3) / 1e12, 2))
+    for name, (ms, passes) in prof.items():
+        if passes:
+            avg = ms / passes
+            kern[name] = dict(avg_ms=round(avg, 4), passes=passes, tflops=round(flops[name] / (avg * 1e-3) / 1e12, 2))
     dominant = max(kern, key=lambda n: kern[n]["avg_ms"]) if kern else None
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the number comes
-    # from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command (profiles/*_pmc_traffic.json)
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["kernels"]
-        key = {"gather_dot": "dau::gather_dot_kernel", "gather_sum_fwd": "dau::gather_mfma_kernel",
-               "gather_sum_dx": "dau::gather_mfma_kernel"}.get(dominant, "")
-        hits = [v["hbm_bytes"] for k, v in pmc.items() if k.startswith(key)] if key and args.workload == "ns" and not args.shape else []
-        traffic = round(hits[0] / 1e9, 3) if hits else None
-    except Exception:
-        traffic = None
     roofline = None
     if dominant:
+        traffic, traffic_note = measured_traffic(wl_key, args.io, dominant)
         ach = flops[dominant] / (kern[dominant]["avg_ms"] * 1e-3) / 1e12
         roofline = dict(bound="mfma", kernel=dominant, achieved=round(ach, 2), peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / FP32_PEAK_TFLOPS, 4), traffic=traffic, traffic_unit="GB per launch (2*FETCH_SIZE+WRITE_SIZE)", kernels=kern,
+                        frac=round(ach / FP32_PEAK_TFLOPS, 4), traffic=traffic, traffic_unit="GB per pass",
+                        traffic_note=traffic_note, kernels=kern,
                         whole_step_tflops=round(32.0 * unit_px * args.steps / elapsed / 1e12, 2))
         # the BASELINE metric also asks for the HBM view: compulsory bytes of one fwd+bwd step (SURVEY.md 8d:
         # e*N*H*W*(3S+2F) + 7*4*S*G*F) over the step time, against the 8 TB/s roof -- ~1 %, the operator is compute bound
@@ -197,16 +305,50 @@ def main():
         roofline["hbm_algorithmic"] = dict(bytes_per_step=step_bytes, achieved_GBps=round(gbps / world, 1), peak_GBps=8000.0,
                                            frac=round(gbps / world / 8000.0, 4))
 
+    # the same step through the drop-in layer: DAUConv2d + autograd with its default offset check ("async": the previous
+    # call's status is read from pinned host memory, no sync) -- what a model built on the Python surface pays
+    layer = None
+    if rank == 0 and world == 1 and not args.no_layer and ignore == 0:
+        import dau_conv
+        torch.cuda.empty_cache()
+        lay = dau_conv.DAUConv2d(filters=F, dau_units=(1, G), max_kernel_size=k, use_bias=False, in_channels=S,
+                                 mu_learning_rate_factor=1.0, dau_sigma_trainable=True).to(dev)
+        with torch.no_grad():
+            lay.weights.copy_(w); lay.mu1.copy_(mu1); lay.mu2.copy_(mu2)
+        xl = x.detach().clone().requires_grad_(True)
+
+        def layer_step():
+            yl = lay(xl)
+            yl.backward(dy)
+            xl.grad = None
+            for p_ in lay.parameters():
+                p_.grad = None
+
+        lsteps = max(2, min(args.steps, 10))
+        for _ in range(2):
+            layer_step()
+        torch.cuda.synchronize()
+        l0 = time.perf_counter()
+        for _ in range(lsteps):
+            layer_step()
+        torch.cuda.synchronize()
+        lms = (time.perf_counter() - l0) / lsteps * 1e3
+        layer = dict(ms_per_step=round(lms, 3), steps=lsteps, check_offsets="async",
+                     note="dau_conv.DAUConv2d forward + autograd backward (all five gradients, sigma trainable)")
+        del lay, xl
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import dau_oracle as orc
-        ncpu = min(N, 32)
-        xs, dys = x[:ncpu].cpu().numpy(), dy[:ncpu].cpu().numpy()
+        # bounded sample (~10-30 s of CPU work): whole images of the same batch, fewer for the big-map workloads
+        per_image = 32.0 * G_live * H * W * S * F
+        ncpu = int(max(1, min(N, 32, round(1.1e13 / per_image))))
+        xs, dys = x[:ncpu].float().cpu().numpy(), dy[:ncpu].float().cpu().numpy()
         wn, m1, m2 = w.cpu().numpy(), mu1.cpu().numpy(), mu2.cpu().numpy()
         orc.forward(xs[:1, :4], wn[:, :4], m1[:, :4], m2[:, :4], 0.5)   # load + warm the library
         c0 = time.perf_counter()
-        orc.forward(xs, wn, m1, m2, 0.5)
-        orc.backward(xs, dys, wn, m1, m2, 0.5, unit_testing=False, mu_learning_rate_factor=1.0)
+        orc.forward(xs, wn, m1, m2, 0.5, ignore=ignore)
+        orc.backward(xs, dys, wn, m1, m2, 0.5, ignore=ignore, unit_testing=False, mu_learning_rate_factor=1.0)
         ct = time.perf_counter() - c0
         cpu = dict(value=round(ncpu * H * W / ct / 1e9, 8), unit="GSamples/s", cores=orc.num_threads(), kind="port",
                    sample="oracle fwd+bwd on the first %d images of the same batch (%.1f s); double accumulation, OpenMP" % (ncpu, ct))
@@ -214,12 +356,18 @@ def main():
     if rank == 0:
         out = dict(metric="DAU fwd+bwd GSamples/s (N*H*W/s)", value=round(value, 6), unit="GSamples/s", n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
-                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   higher_is_better=True, scaling="weak", vs_baseline=None,
+                   dtype=args.io, accumulate="f32", data="synthetic",
+                   ranks_seen=(dist.get_world_size() if use_dist else 1),
+                   comm=(dict(backend=("rccl" if backend == "nccl" else backend), communicator_size=dist.get_world_size(),
+                              exchange="all_reduce(sum) of raw param-grad sums [4,S,G,F] = %d floats per step, async under the dx pass; finalize after"
+                              % (4 * S * G * F)) if use_dist else None),
                    config=dict(workload=wl["label"] + (" [bf16 activations in HBM]" if args.io == "bf16" else "") +
                                ("" if backend == "nccl" else " [REHEARSAL: %s backend, ranks share GPUs]" % backend),
                                global_batch=N * world, parallelism="dp%d" % world,
-                               algo_forward=plan.info["algo_forward"], algo_backward=plan.info["algo_backward"]),
-                   roofline=roofline, cpu_baseline=cpu)
+                               algo_forward=plan.info["algo_forward"], algo_backward=plan.info["algo_backward"],
+                               static_offset_bucket=plan.info["offset_bucket"], bucket_sets=plan.info["bucket_sets"]),
+                   roofline=roofline, cpu_baseline=cpu, layer=layer, parity_gate=parity, lib=lib_fingerprint())
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -17,7 +17,9 @@ __device__ __forceinline__ void store_act(float* base, long idx, float v, bool b
     unsigned short* p = reinterpret_cast<unsigned short*>(base) + idx;
     if (accumulate) v += __uint_as_float((unsigned)*p << 16);
     unsigned u = __float_as_uint(v);
-    u += 0x7fffu + ((u >> 16) & 1u);               // round to nearest even (NaN stays NaN: the payload only grows)
+    // round to nearest even on the bits; a NaN must stay a NaN (the rounding add can carry a NaN payload into the sign /
+    // exponent: 0xFFFFFFFF -> +0, 0x7F800001 -> +inf), so it is stored as the quiet NaN pattern instead
+    u = (v != v) ? 0x7fc00000u : u + 0x7fffu + ((u >> 16) & 1u);
     *p = (unsigned short)(u >> 16);
 }
 
@@ -40,6 +42,21 @@ struct Status {
     unsigned int pad[2];
 };
 
+// Offset-bucket guard of a launch.  The bucket a call needs depends on max|mu|, which only the device knows when the
+// kernels are enqueued (prepare_units_kernel leaves it in the status block).  The host enqueues the kernel sets of up to
+// two candidate buckets; every kernel of a set starts with guard_pass() and returns at once unless the actual max|mu|
+// falls into (lo, hi] -- exactly one set does the work, without a device->host sync (the reference blocks on a D2H copy
+// of the amax for this, dau_conv_op.cpp:229-253).  status == nullptr: unguarded.
+struct Guard {
+    const Status* status;
+    float lo, hi;
+};
+__device__ __forceinline__ bool guard_pass(const Guard& g) {
+    if (!g.status) return true;
+    const float mx = __uint_as_float(g.status->max_abs_mu_bits);
+    return mx > g.lo && mx <= g.hi;
+}
+
 // One prepared unit for the gather kernels: integer displacement and the four
 // bilinear weights already multiplied by w (dau_conv_forward_core.hpp:2155-2213).
 struct UnitRef {
@@ -54,10 +71,12 @@ struct Shape {
 // ---- launchers implemented in the kernel TUs --------------------------------------
 // k_filters.hip
 void launch_synth_filters(hipStream_t st, const float* sigma_dev, int k, int flags, float* filters6);
+void launch_synth_filters_compact(hipStream_t st, const float* sigma_dev, int k, int flags, float* planes6);
 // k_units.hip
+// host_status (may be null): pinned host copy of the status block, written by the last workgroup to finish
 void launch_prepare_units(hipStream_t st, const float* w, const float* mu1, const float* mu2, Shape sh,
                           int ignore, int flags, int bucket, bool transposed_negated, UnitRef* table,
-                          Status* status);
+                          Status* status, Status* host_status);
 void launch_unit_table_export(hipStream_t st, const float* mu1, const float* mu2, long units, int flags,
                               int32_t* offsets, float* factors);
 void launch_finalize_grads(hipStream_t st, const float* r4, const float* w, Shape sh, int ignore, float lr,

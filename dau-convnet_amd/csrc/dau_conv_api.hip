@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
@@ -64,21 +65,40 @@ int edge_disabled(int size) {
 
 }  // namespace
 
-struct dau_conv_plan {
-    dau_conv_desc d;
-    Shape sh;
-    int bucket;        // offset bucket R
-    int blur_k;        // prefilter support
-    int drop_col, drop_row;
-    int algo_fwd, algo_bwd;
+// The tiled kernels of one offset bucket.  A plan holds one set per bucket up to the static one (the bucket
+// max_kernel_size allows); which set runs is decided per call from the actual max|mu| (see run_sets below).
+struct BucketSet {
+    int bucket = 0;
+    bool fwd_ok = false, dot_ok = false;
     TiledConfig tiled_fwd;   // gather-sum y  : S -> F
     TiledConfig tiled_dx;    // gather-sum dx : F -> S
     TiledDotConfig tiled_dot;
+};
+constexpr int kBuckets[] = {4, 8, 16, 24, 32};
+constexpr int kNumBuckets = 5;
+
+struct dau_conv_plan {
+    dau_conv_desc d;
+    Shape sh;
+    int bucket;        // static offset bucket R: the largest displacement max_kernel_size allows
+    int blur_k;        // prefilter support
+    int drop_col, drop_row;
+    int algo_fwd, algo_bwd;
+    int nsets = 0;             // bucket sets, ascending; sets[nsets - 1] is the static bucket
+    BucketSet sets[kNumBuckets];
+    bool dynamic = false;      // pick the set from the actual offsets (tiled kernels only)
+    // pinned host mirror of the status block of the most recent completed call: {max|mu| bits, nan, valid, -}.  It is
+    // the offset-bucket hint of the next call and what dau_conv_last_status reports; a stale or torn value only costs
+    // speed, never correctness (the device-side guards decide which set really runs).
+    Status* host_status = nullptr;
+    mutable bool attrs_set = false;   // dynamic-LDS limits raised on this device (first call)
+    const BucketSet& top() const { return sets[nsets - 1]; }
     long units() const { return (long)sh.S * sh.G * sh.F; }
     // optional benchmark timing (dau_conv_profile_begin/_end); mutable because the passes take a const plan
     mutable bool profiling = false;
     mutable std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[DAU_PROFILE_SLOTS];
     mutable size_t prof_used[DAU_PROFILE_SLOTS] = {0, 0, 0};
+    mutable int prof_passes[DAU_PROFILE_SLOTS] = {0, 0, 0};   // passes (a pass may take several window launches)
 };
 
 namespace {
@@ -107,6 +127,48 @@ struct ProfScope {
     }
 };
 
+// The bucket sets one call enqueues.  Without a hint (first call, dynamic selection off) it is the static set, unguarded.
+// With a hint -- max|mu| of the most recent completed call, read from pinned host memory without a sync -- it is the
+// smallest set that covers the hint, guarded by (-1, R_hint], followed by the static set guarded by (R_hint, inf): the
+// device decides between them from the max|mu| of THIS call, so results never depend on the hint.  This replaces the
+// reference's blocking amax + D2H copy per call (dau_conv_op.cpp:223-253) and makes a layer with a large
+// max_kernel_size but small offsets run the small-offset kernels (the reference's tests rely on that,
+// dau_conv_test.py:433,436).
+struct Candidate {
+    const BucketSet* set;
+    Guard guard;
+};
+
+// pass_kind: 0 = gather-sum (needs fwd_ok), 1 = gather-dot (needs dot_ok)
+int pick_candidates(const dau_conv_plan* p, const Status* dev_status, int pass_kind, Candidate out[2]) {
+    const BucketSet* top = &p->top();
+    out[0] = Candidate{top, Guard{nullptr, 0.0f, 0.0f}};
+    if (!p->dynamic || !p->host_status || p->nsets < 2) return 1;
+    const volatile unsigned* h = reinterpret_cast<const volatile unsigned*>(p->host_status);
+    if (h[2] != 1u || h[1] != 0u) return 1;
+    float mx;
+    const unsigned bits = h[0];
+    std::memcpy(&mx, &bits, sizeof(float));
+    if (!(mx >= 0.0f)) return 1;
+    for (int i = 0; i + 1 < p->nsets; ++i) {
+        const BucketSet& b = p->sets[i];
+        if (mx > (float)b.bucket || !(pass_kind == 0 ? b.fwd_ok : b.dot_ok)) continue;
+        out[0] = Candidate{&b, Guard{dev_status, -1.0f, (float)b.bucket}};
+        out[1] = Candidate{top, Guard{dev_status, (float)b.bucket, INFINITY}};
+        return 2;
+    }
+    return 1;
+}
+
+void ensure_attrs(const dau_conv_plan* p) {
+    if (p->attrs_set) return;
+    for (int i = 0; i < p->nsets; ++i) {
+        if (p->sets[i].fwd_ok) { tiled_gather_init(p->sets[i].tiled_fwd); tiled_gather_init(p->sets[i].tiled_dx); }
+        if (p->sets[i].dot_ok) tiled_dot_init(p->sets[i].tiled_dot);
+    }
+    p->attrs_set = true;
+}
+
 struct FwdWs {
     Status* status;
     float* filters;
@@ -123,7 +185,10 @@ FwdWs carve_forward(const dau_conv_plan* p, void* ws) {
     w.filters = c.take<float>(kFilterFloats);
     w.table = c.take<UnitRef>(p->units());
     if (p->algo_fwd == DAU_ALGO_TILED) {
-        w.tiled = c.take<char>(tiled_gather_workspace_bytes(p->tiled_fwd));
+        size_t need = 0;
+        for (int i = 0; i < p->nsets; ++i)
+            if (p->sets[i].fwd_ok) need = std::max(need, tiled_gather_workspace_bytes(p->sets[i].tiled_fwd));
+        w.tiled = c.take<char>(need);
     } else {
         w.xb = c.take<float>((size_t)p->sh.N * p->sh.S * p->sh.H * p->sh.W);
     }
@@ -154,12 +219,18 @@ BwdWs carve_backward(const dau_conv_plan* p, void* ws) {
     w.table_t = c.take<UnitRef>(p->units());
     w.r4 = c.take<float>(kNumK * p->units());
     if (p->algo_bwd == DAU_ALGO_TILED) {
-        w.tiled_dot = c.take<char>(tiled_dot_workspace_bytes(p->tiled_dot));
+        size_t need = 0;
+        for (int i = 0; i < p->nsets; ++i)
+            if (p->sets[i].dot_ok) need = std::max(need, tiled_dot_workspace_bytes(p->sets[i].tiled_dot));
+        w.tiled_dot = c.take<char>(need);
     } else {
         w.xk4 = c.take<float>((size_t)kNumK * s.N * s.S * s.H * s.W);
     }
     if (p->algo_fwd == DAU_ALGO_TILED) {
-        w.tiled_dx = c.take<char>(tiled_gather_workspace_bytes(p->tiled_dx));
+        size_t need = 0;
+        for (int i = 0; i < p->nsets; ++i)
+            if (p->sets[i].fwd_ok) need = std::max(need, tiled_gather_workspace_bytes(p->sets[i].tiled_dx));
+        w.tiled_dx = c.take<char>(need);
     } else {
         w.eb = c.take<float>((size_t)s.N * s.F * s.H * s.W);
     }
@@ -192,6 +263,7 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
     if (half <= 4) bucket = 4;
     else if (half <= 8) bucket = 8;
     else if (half <= 16) bucket = 16;
+    else if (half <= 24) bucket = 24;
     else if (half <= 32) bucket = 32;
     else
         return fail(DAU_INVALID_ARGUMENT,
@@ -216,9 +288,15 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
 
     const Shape& s = p->sh;
     const bool bf16 = (desc->flags & DAU_FLAG_IO_BF16) != 0;
-    const bool fwd_ok = tiled_gather_configure(s.N, s.S, s.F, s.G, s.H, s.W, bucket, blur_k, bf16, &p->tiled_fwd) &&
-                        tiled_gather_configure(s.N, s.F, s.S, s.G, s.H, s.W, bucket, blur_k, bf16, &p->tiled_dx);
-    const bool dot_ok = tiled_dot_configure(s, bucket, blur_k, bf16, &p->tiled_dot);
+    for (int b : kBuckets) {
+        if (b > bucket) break;
+        BucketSet& bs = p->sets[p->nsets++];
+        bs.bucket = b;
+        bs.fwd_ok = tiled_gather_configure(s.N, s.S, s.F, s.G, s.H, s.W, b, blur_k, bf16, &bs.tiled_fwd) &&
+                    tiled_gather_configure(s.N, s.F, s.S, s.G, s.H, s.W, b, blur_k, bf16, &bs.tiled_dx);
+        bs.dot_ok = tiled_dot_configure(s, b, blur_k, bf16, desc->number_units_ignore, &bs.tiled_dot);
+    }
+    const bool fwd_ok = p->top().fwd_ok, dot_ok = p->top().dot_ok;
     if (bf16 && (desc->algo == DAU_ALGO_DIRECT || !(fwd_ok && dot_ok))) {
         delete p;
         return fail(DAU_INVALID_ARGUMENT, "DAU_FLAG_IO_BF16 needs the tiled kernels, which do not support this shape / algo");
@@ -229,14 +307,29 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
     }
     p->algo_fwd = (desc->algo != DAU_ALGO_DIRECT && fwd_ok) ? DAU_ALGO_TILED : DAU_ALGO_DIRECT;
     p->algo_bwd = (desc->algo != DAU_ALGO_DIRECT && dot_ok) ? DAU_ALGO_TILED : DAU_ALGO_DIRECT;
+    // dynamic bucket selection: tiled kernels, more than one bucket, not switched off (flag, or DAU_DYNAMIC_BUCKET=0 in
+    // the environment at plan creation: A/B timing).  The pinned status mirror needs a device; without one (header-only
+    // checks on a CPU box) the plan simply has no hint.
+    const char* env = getenv("DAU_DYNAMIC_BUCKET");
+    p->dynamic = p->nsets > 1 && !(desc->flags & DAU_FLAG_STATIC_BUCKET) && !(env && atoi(env) == 0) &&
+                 (p->algo_fwd == DAU_ALGO_TILED || p->algo_bwd == DAU_ALGO_TILED);
+    void* hs = nullptr;
+    if (hipHostMalloc(&hs, sizeof(Status), hipHostMallocDefault) == hipSuccess && hs) {
+        std::memset(hs, 0, sizeof(Status));
+        p->host_status = static_cast<Status*>(hs);
+    } else {
+        (void)hipGetLastError();   // no device: not an error of this call
+    }
     *plan_out = p;
     return DAU_OK;
 }
 
 int dau_conv_plan_destroy(dau_conv_plan* plan) {
-    if (plan)
+    if (plan) {
         for (auto& pool : plan->prof_events)
             for (auto& ev : pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+        if (plan->host_status) (void)hipHostFree(plan->host_status);
+    }
     delete plan;
     return DAU_OK;
 }
@@ -244,12 +337,13 @@ int dau_conv_plan_destroy(dau_conv_plan* plan) {
 int dau_conv_profile_begin(dau_conv_plan* plan) {
     if (!plan) return fail(DAU_INVALID_ARGUMENT, "null argument");
     for (size_t& u : plan->prof_used) u = 0;
+    for (int& n : plan->prof_passes) n = 0;
     plan->profiling = true;
     return DAU_OK;
 }
 
-int dau_conv_profile_end(dau_conv_plan* plan, double* ms_out, int32_t* launches_out) {
-    if (!plan || !ms_out || !launches_out) return fail(DAU_INVALID_ARGUMENT, "null argument");
+int dau_conv_profile_end(dau_conv_plan* plan, double* ms_out, int32_t* passes_out) {
+    if (!plan || !ms_out || !passes_out) return fail(DAU_INVALID_ARGUMENT, "null argument");
     plan->profiling = false;
     for (int slot = 0; slot < DAU_PROFILE_SLOTS; ++slot) {
         double total = 0.0;
@@ -261,8 +355,9 @@ int dau_conv_profile_end(dau_conv_plan* plan, double* ms_out, int32_t* launches_
             total += ms;
         }
         ms_out[slot] = total;
-        launches_out[slot] = (int32_t)plan->prof_used[slot];
+        passes_out[slot] = plan->prof_passes[slot];
         plan->prof_used[slot] = 0;
+        plan->prof_passes[slot] = 0;
     }
     return DAU_OK;
 }
@@ -275,9 +370,11 @@ int dau_conv_plan_get_info(const dau_conv_plan* plan, dau_conv_plan_info* info) 
     info->algo_backward = plan->algo_bwd;
     info->drop_last_col = plan->drop_col;
     info->drop_last_row = plan->drop_row;
-    info->gather_patch = plan->algo_fwd == DAU_ALGO_TILED ? plan->tiled_fwd.tiles_x * 8 : 0;
-    info->gather_stack = plan->algo_fwd == DAU_ALGO_TILED ? plan->tiled_fwd.stack : 0;
-    info->dot_windows = plan->algo_bwd == DAU_ALGO_TILED ? plan->tiled_dot.windows : 0;
+    info->gather_patch = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.tiles_x * 8 : 0;
+    info->gather_stack = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.stack : 0;
+    info->dot_windows = plan->algo_bwd == DAU_ALGO_TILED ? plan->top().tiled_dot.windows : 0;
+    info->gather_windows = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.windows : 0;
+    info->bucket_sets = plan->dynamic ? plan->nsets : 1;
     return DAU_OK;
 }
 
@@ -297,23 +394,68 @@ int dau_conv_forward(const dau_conv_plan* p, void* stream, const float* x, const
         return fail(DAU_INVALID_ARGUMENT, "workspace too small: %zu < %zu", workspace_bytes, ws.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Shape& s = p->sh;
+    ensure_attrs(p);
     DAU_HIP(hipMemsetAsync(ws.status, 0, sizeof(Status), st));
     launch_synth_filters(st, sigma, p->blur_k, p->d.flags, ws.filters);
-    launch_prepare_units(st, w, mu1, mu2, s, p->d.number_units_ignore, p->d.flags, p->bucket, false, ws.table, ws.status);
+    launch_prepare_units(st, w, mu1, mu2, s, p->d.number_units_ignore, p->d.flags, p->bucket, false, ws.table, ws.status,
+                         p->host_status);
     if (p->algo_fwd == DAU_ALGO_TILED) {
-        for (int window = 0; window < tiled_gather_windows(p->tiled_fwd); ++window) {   // one pass unless the bucket is 32
-            tiled_gather_prepare(st, p->tiled_fwd, x, ws.filters, false, ws.table, ws.tiled, window);
-            ProfScope prof(p, 0, st);
-            tiled_gather_run(st, p->tiled_fwd, y, ws.tiled, window > 0);
+        Candidate cand[2];
+        const int ncand = pick_candidates(p, ws.status, 0, cand);
+        if (p->profiling) ++p->prof_passes[0];
+        for (int ci = 0; ci < ncand; ++ci) {
+            const TiledConfig& cfg = cand[ci].set->tiled_fwd;
+            for (int window = 0; window < tiled_gather_windows(cfg); ++window) {   // one pass unless the bucket is 24 or 32
+                tiled_gather_prepare(st, cfg, x, ws.filters, false, ws.table, ws.tiled, window, cand[ci].guard);
+                ProfScope prof(p, 0, st);
+                tiled_gather_run(st, cfg, y, ws.tiled, window > 0, cand[ci].guard);
+            }
         }
     } else {
         launch_blur_direct(st, x, (long)s.N * s.S, s.H, s.W, ws.filters + 0 * kFilterPlane, 1, p->blur_k, ws.xb);
+        if (p->profiling) ++p->prof_passes[0];
         ProfScope prof(p, 0, st);
         launch_gather_sum_direct(st, ws.xb, ws.table, s.N, s.S, s.F, s.G, s.H, s.W, y);
     }
     DAU_HIP(hipPeekAtLastError());
     return DAU_OK;
 }
+
+namespace {
+
+// raw parameter-gradient sums r4[k][s][g][f] = offset_and_dot(x * D_k, dy') with bare bilinear factors
+int run_param_sums(const dau_conv_plan* p, hipStream_t st, const float* x, const float* dy, const float* mu1,
+                   const float* mu2, const BwdWs& ws, float* r4) {
+    const Shape& s = p->sh;
+    const int flags = p->d.flags;
+    launch_prepare_units(st, nullptr, mu1, mu2, s, p->d.number_units_ignore, flags, p->bucket, false, ws.table_bare,
+                         ws.status, p->host_status);
+    if (p->profiling) ++p->prof_passes[2];
+    if (p->algo_bwd == DAU_ALGO_TILED) {
+        Candidate cand[2];
+        const int ncand = pick_candidates(p, ws.status, 1, cand);
+        for (int ci = 0; ci < ncand; ++ci) {
+            const TiledDotConfig& cfg = cand[ci].set->tiled_dot;
+            tiled_dot_prepare(st, cfg, x, dy, ws.filters, ws.table_bare, p->drop_col, p->drop_row, ws.tiled_dot, cand[ci].guard);
+            ProfScope prof(p, 2, st);
+            tiled_dot_run(st, cfg, r4, ws.tiled_dot, cand[ci].guard);
+        }
+    } else {
+        launch_blur_direct(st, x, (long)s.N * s.S, s.H, s.W, ws.filters + 1 * kFilterPlane, kNumK, p->blur_k, ws.xk4);
+        ProfScope prof(p, 2, st);
+        launch_gather_dot_direct(st, ws.xk4, dy, ws.table_bare, s, p->drop_col, p->drop_row, r4);
+    }
+    return DAU_OK;
+}
+
+int check_backward_ws(const dau_conv_plan* p, void* workspace, size_t workspace_bytes, BwdWs* ws) {
+    *ws = carve_backward(p, workspace);
+    if (workspace_bytes < ws->bytes)
+        return fail(DAU_INVALID_ARGUMENT, "workspace too small: %zu < %zu", workspace_bytes, ws->bytes);
+    return DAU_OK;
+}
+
+}  // namespace
 
 int dau_conv_backward(const dau_conv_plan* p, void* stream, const float* x, const float* dy, const float* w,
                       const float* mu1, const float* mu2, const float* sigma, float* dx, float* dw, float* dmu1,
@@ -323,43 +465,38 @@ int dau_conv_backward(const dau_conv_plan* p, void* stream, const float* x, cons
         ((need_mask & DAU_NEED_DMU1) && !dmu1) || ((need_mask & DAU_NEED_DMU2) && !dmu2) ||
         ((need_mask & DAU_NEED_DSIGMA) && !dsigma))
         return fail(DAU_INVALID_ARGUMENT, "need_mask asks for a gradient whose output pointer is null");
-    BwdWs ws = carve_backward(p, workspace);
-    if (workspace_bytes < ws.bytes)
-        return fail(DAU_INVALID_ARGUMENT, "workspace too small: %zu < %zu", workspace_bytes, ws.bytes);
+    BwdWs ws;
+    if (int rc = check_backward_ws(p, workspace, workspace_bytes, &ws)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Shape& s = p->sh;
     const int flags = p->d.flags;
+    ensure_attrs(p);
     DAU_HIP(hipMemsetAsync(ws.status, 0, sizeof(Status), st));
     launch_synth_filters(st, sigma, p->blur_k, flags, ws.filters);
 
     const int param_mask = DAU_NEED_DW | DAU_NEED_DMU1 | DAU_NEED_DMU2 | DAU_NEED_DSIGMA;
     if (need_mask & param_mask) {
-        // parameter gradients: r_k = offset_and_dot(x * D_k, dy') with bare bilinear factors
-        launch_prepare_units(st, nullptr, mu1, mu2, s, p->d.number_units_ignore, flags, p->bucket, false, ws.table_bare,
-                             ws.status);
-        if (p->algo_bwd == DAU_ALGO_TILED) {
-            tiled_dot_prepare(st, p->tiled_dot, x, dy, ws.filters, ws.table_bare, p->drop_col,
-                              p->drop_row, ws.tiled_dot);
-            ProfScope prof(p, 2, st);
-            tiled_dot_run(st, p->tiled_dot, ws.r4, ws.tiled_dot);
-        } else {
-            launch_blur_direct(st, x, (long)s.N * s.S, s.H, s.W, ws.filters + 1 * kFilterPlane, kNumK, p->blur_k, ws.xk4);
-            ProfScope prof(p, 2, st);
-            launch_gather_dot_direct(st, ws.xk4, dy, ws.table_bare, s, p->drop_col, p->drop_row, ws.r4);
-        }
+        run_param_sums(p, st, x, dy, mu1, mu2, ws, ws.r4);
         launch_finalize_grads(st, ws.r4, w, s, p->d.number_units_ignore, p->d.mu_learning_rate_factor, need_mask,
                               flags & DAU_FLAG_SINGLE_DIM_KERNEL, dw, dmu1, dmu2, dsigma);
     }
     if (need_mask & DAU_NEED_DX) {
         // input gradient: the forward gather on the mirrored-Gaussian-blurred error with the
         // parameters read as [F,G,S] and negated offsets (base_dau_conv_layer.cu:299-325)
-        launch_prepare_units(st, w, mu1, mu2, s, 0, flags, p->bucket, true, ws.table_t,
-                             (need_mask & param_mask) ? nullptr : ws.status);
+        const bool fresh = !(need_mask & param_mask);     // this call has not looked at the offsets yet
+        launch_prepare_units(st, w, mu1, mu2, s, 0, flags, p->bucket, true, ws.table_t, fresh ? ws.status : nullptr,
+                             p->host_status);
+        if (p->profiling) ++p->prof_passes[1];
         if (p->algo_fwd == DAU_ALGO_TILED) {
-            for (int window = 0; window < tiled_gather_windows(p->tiled_dx); ++window) {
-                tiled_gather_prepare(st, p->tiled_dx, dy, ws.filters, true, ws.table_t, ws.tiled_dx, window);
-                ProfScope prof(p, 1, st);
-                tiled_gather_run(st, p->tiled_dx, dx, ws.tiled_dx, window > 0);
+            Candidate cand[2];
+            const int ncand = pick_candidates(p, ws.status, 0, cand);
+            for (int ci = 0; ci < ncand; ++ci) {
+                const TiledConfig& cfg = cand[ci].set->tiled_dx;
+                for (int window = 0; window < tiled_gather_windows(cfg); ++window) {
+                    tiled_gather_prepare(st, cfg, dy, ws.filters, true, ws.table_t, ws.tiled_dx, window, cand[ci].guard);
+                    ProfScope prof(p, 1, st);
+                    tiled_gather_run(st, cfg, dx, ws.tiled_dx, window > 0, cand[ci].guard);
+                }
             }
         } else {
             launch_blur_direct(st, dy, (long)s.N * s.F, s.H, s.W, ws.filters + 5 * kFilterPlane, 1, p->blur_k, ws.eb);
@@ -367,6 +504,34 @@ int dau_conv_backward(const dau_conv_plan* p, void* stream, const float* x, cons
             launch_gather_sum_direct(st, ws.eb, ws.table_t, s.N, s.F, s.S, s.G, s.H, s.W, dx);
         }
     }
+    DAU_HIP(hipPeekAtLastError());
+    return DAU_OK;
+}
+
+int dau_conv_backward_param_sums(const dau_conv_plan* p, void* stream, const float* x, const float* dy, const float* mu1,
+                                 const float* mu2, const float* sigma, float* sums_out, void* workspace,
+                                 size_t workspace_bytes) {
+    if (!p || !x || !dy || !mu1 || !mu2 || !sigma || !sums_out || !workspace) return fail(DAU_INVALID_ARGUMENT, "null argument");
+    BwdWs ws;
+    if (int rc = check_backward_ws(p, workspace, workspace_bytes, &ws)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ensure_attrs(p);
+    DAU_HIP(hipMemsetAsync(ws.status, 0, sizeof(Status), st));
+    launch_synth_filters(st, sigma, p->blur_k, p->d.flags, ws.filters);
+    run_param_sums(p, st, x, dy, mu1, mu2, ws, sums_out);
+    DAU_HIP(hipPeekAtLastError());
+    return DAU_OK;
+}
+
+int dau_conv_finalize_param_grads(const dau_conv_plan* p, void* stream, const float* sums, const float* w, float* dw,
+                                  float* dmu1, float* dmu2, float* dsigma, int need_mask) {
+    if (!p || !sums || !w) return fail(DAU_INVALID_ARGUMENT, "null argument");
+    if (((need_mask & DAU_NEED_DW) && !dw) || ((need_mask & DAU_NEED_DMU1) && !dmu1) ||
+        ((need_mask & DAU_NEED_DMU2) && !dmu2) || ((need_mask & DAU_NEED_DSIGMA) && !dsigma))
+        return fail(DAU_INVALID_ARGUMENT, "need_mask asks for a gradient whose output pointer is null");
+    launch_finalize_grads(static_cast<hipStream_t>(stream), sums, w, p->sh, p->d.number_units_ignore,
+                          p->d.mu_learning_rate_factor, need_mask, p->d.flags & DAU_FLAG_SINGLE_DIM_KERNEL, dw, dmu1, dmu2,
+                          dsigma);
     DAU_HIP(hipPeekAtLastError());
     return DAU_OK;
 }
@@ -388,18 +553,32 @@ int dau_conv_check_status(const dau_conv_plan* p, void* stream, const void* work
     return DAU_OK;
 }
 
+int dau_conv_last_status(const dau_conv_plan* p, float* max_abs_mu_out, int32_t* valid_out) {
+    if (!p) return fail(DAU_INVALID_ARGUMENT, "null argument");
+    if (max_abs_mu_out) *max_abs_mu_out = 0.0f;
+    if (valid_out) *valid_out = 0;
+    if (!p->host_status) return DAU_OK;
+    const volatile unsigned* h = reinterpret_cast<const volatile unsigned*>(p->host_status);
+    if (h[2] != 1u) return DAU_OK;                       // no call has completed yet
+    const unsigned bits = h[0], nan_seen = h[1];
+    float mx;
+    std::memcpy(&mx, &bits, sizeof(float));
+    if (max_abs_mu_out) *max_abs_mu_out = mx;
+    if (valid_out) *valid_out = 1;
+    if (nan_seen) return fail(DAU_FAILED_PRECONDITION, "DAUConvOp ERROR: got NaN value in offset (mu1,mu2) variable");
+    if (mx > (float)p->bucket)
+        return fail(DAU_INVALID_ARGUMENT,
+                    "DAUConvOp ERROR: actual offsets (%.3f) larger than what max_kernel_size=%d allows (setup max_kernel_size "
+                    "and dau_unit_border_bound correctly to avoid this)",
+                    mx, p->d.max_kernel_size);
+    return DAU_OK;
+}
+
 int dau_conv_filters(const dau_conv_plan* p, void* stream, const float* sigma, float* filters_out) {
     if (!p || !sigma || !filters_out) return fail(DAU_INVALID_ARGUMENT, "null argument");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    // synthesise into a scratch with the fixed plane pitch, then compact to k*k planes
-    float* tmp = nullptr;
-    DAU_HIP(hipMalloc(&tmp, sizeof(float) * kFilterFloats));
-    launch_synth_filters(st, sigma, p->blur_k, p->d.flags, tmp);
-    const size_t plane = sizeof(float) * p->blur_k * p->blur_k;
-    hipError_t e = hipMemcpy2DAsync(filters_out, plane, tmp, sizeof(float) * kFilterPlane, plane, 6, hipMemcpyDeviceToDevice, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    (void)hipFree(tmp);
-    if (e != hipSuccess) return fail(DAU_INTERNAL, "dau_conv_filters: %s", hipGetErrorString(e));
+    // the six k x k planes are written straight into the caller's buffer: no scratch, no sync
+    launch_synth_filters_compact(static_cast<hipStream_t>(stream), sigma, p->blur_k, p->d.flags, filters_out);
+    DAU_HIP(hipPeekAtLastError());
     return DAU_OK;
 }
 

@@ -13,7 +13,8 @@ struct TiledConfig {
     int R;            // offset bucket
     int blur_k;       // prefilter support
     int NP;           // image pairs = ceil(N/2)
-    int windows;      // gather passes: 1, or 4 offset windows of radius 16 for bucket 32
+    int windows;      // gather passes: 1, or 4 offset windows of radius R/2 for buckets 24 and 32 (every unit belongs to
+                      // exactly one window; a pass gathers only its own units)
     int stack;        // (image pair, patch) planes gathered per workgroup
     int patches;      // patches per image: big or odd-sized images are gathered patch by patch
     int rows, pitch;  // staged plane of a patch: rows = ph + 2R + 1, pitch (in positions) >= pw + 2R + 1 with pitch % 32 == 8
@@ -31,26 +32,33 @@ size_t tiled_gather_workspace_bytes(const TiledConfig& cfg);
 // unit table (`table` is indexed [Cin][G][Cout]).  run: the gather itself, writing `out` ([N,Cout,H,W]).
 int tiled_gather_windows(const TiledConfig& cfg);
 // one pass per offset window: prepare(window) then run(accumulate = window > 0)
+// guard: see dau_common.hpp (every kernel of the pass returns at once unless max|mu| lies in the guard's range)
 void tiled_gather_prepare(hipStream_t st, const TiledConfig& cfg, const float* in, const float* filters, bool mirrored,
-                          const UnitRef* table, void* workspace, int window);
-void tiled_gather_run(hipStream_t st, const TiledConfig& cfg, float* out, void* workspace, bool accumulate);
+                          const UnitRef* table, void* workspace, int window, const Guard& guard);
+void tiled_gather_run(hipStream_t st, const TiledConfig& cfg, float* out, void* workspace, bool accumulate, const Guard& guard);
+// once per plan and device, before the first run: raises the kernels' dynamic-LDS limit
+void tiled_gather_init(const TiledConfig& cfg);
 
 struct TiledDotConfig {
     Shape sh;
     int R, blur_k;
     int NP;
     int variant;
-    int windows;      // offset-window passes: 1 for R <= 8, 4 for R = 16, 16 for R = 32
+    int windows;      // offset windows of radius 8: 1 for R <= 8, 4 for R = 16, 9 for R = 24, 16 for R = 32; with more than
+                      // one window the units are binned by window on the device and a window pass visits only its own
     bool as1, one_tile;   // tuning choices read from the environment at plan creation
     bool bf16;            // x and dy are bfloat16
+    int ignore;           // number_units_ignore: binned window passes give those units no slot
     int debug;
 };
 
-bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, TiledDotConfig* cfg);
+bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, int ignore, TiledDotConfig* cfg);
 size_t tiled_dot_workspace_bytes(const TiledDotConfig& cfg);
 // r4[k][s][g][f] = sum_{n,p} dy'[n,f,p] * bilinear(x * D_k, p + o);  `filters` = output of launch_synth_filters.
 void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& cfg, const float* x, const float* dy,
-                       const float* filters, const UnitRef* table_bare, int drop_col, int drop_row, void* workspace);
-void tiled_dot_run(hipStream_t st, const TiledDotConfig& cfg, float* r4, void* workspace);
+                       const float* filters, const UnitRef* table_bare, int drop_col, int drop_row, void* workspace,
+                       const Guard& guard);
+void tiled_dot_run(hipStream_t st, const TiledDotConfig& cfg, float* r4, void* workspace, const Guard& guard);
+void tiled_dot_init(const TiledDotConfig& cfg);
 
 }  // namespace dau

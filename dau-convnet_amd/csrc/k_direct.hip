@@ -56,11 +56,12 @@ void launch_blur_direct(hipStream_t st, const float* x, long planes, int H, int 
 
 // ---- offset-and-sum: y[n,f,p] = sum_{s,g} sum_taps w' * xb[n,s,p+o+tap] -------------------
 // block = 256 pixels of one (n,f) plane; the unit table entry is wave-uniform (scalar loads).
+// The grid is one-dimensional over (n*Fout + f, pixel block): grid.y would cap N*Fout at 65535.
 __global__ void gather_sum_direct_kernel(const float* __restrict__ xb, const UnitRef* __restrict__ table,
-                                         int Sin, int Fout, int G, int H, int W, float* __restrict__ y) {
-    const int nf = blockIdx.y;
+                                         int Sin, int Fout, int G, int H, int W, int pxblocks, float* __restrict__ y) {
+    const int nf = blockIdx.x / pxblocks;
     const int n = nf / Fout, f = nf % Fout;
-    const int px = blockIdx.x * blockDim.x + threadIdx.x;
+    const int px = (blockIdx.x % pxblocks) * blockDim.x + threadIdx.x;
     const long HW = (long)H * W;
     if (px >= HW) return;
     const int yy = px / W, xx = px % W;
@@ -91,8 +92,9 @@ void launch_gather_sum_direct(hipStream_t st, const float* xb, const UnitRef* ta
     // table is indexed [Sin][G][Fout] (f fastest) for both passes
     const int block = 256;
     const long HW = (long)H * W;
-    dim3 grid((unsigned)((HW + block - 1) / block), (unsigned)(N * Fout));
-    hipLaunchKernelGGL(gather_sum_direct_kernel, grid, dim3(block), 0, st, xb, table, Sin, Fout, G, H, W, y);
+    const int pxblocks = (int)((HW + block - 1) / block);
+    dim3 grid((unsigned)((long)pxblocks * N * Fout));
+    hipLaunchKernelGGL(gather_sum_direct_kernel, grid, dim3(block), 0, st, xb, table, Sin, Fout, G, H, W, pxblocks, y);
 }
 
 // ---- offset-and-dot: r_k[s,g,f] = sum_{n,p} err'[n,f,p] * bilinear(xk[n,s,k], p + o) ---------

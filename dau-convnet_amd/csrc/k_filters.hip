@@ -6,8 +6,9 @@
 
 namespace dau {
 
-__global__ void synth_filters_kernel(const float* __restrict__ sigma_dev, int k, int flags,
-                                     float* __restrict__ out) {
+// plane_pitch: floats between the six 2-D planes of `out`; taps: the eight 1-D factor arrays (may be null)
+__global__ void synth_filters_kernel(const float* __restrict__ sigma_dev, int k, int flags, int plane_pitch,
+                                     float* __restrict__ out, float* __restrict__ taps) {
     // one wave; lane t strides over the k*k taps, sums via wave reduction
     const int lane = threadIdx.x;
     const int n = k * k, c = (k - 1) / 2;
@@ -34,15 +35,15 @@ __global__ void synth_filters_kernel(const float* __restrict__ sigma_dev, int k,
         if (single_dim && v != 0) g = 0;
         if (forbid_pos && u > 0) g = 0;
         const double gn = g / Z;
-        out[0 * kFilterPlane + t] = (float)gn;                                        // Gn
-        out[1 * kFilterPlane + t] = (float)gn;                                        // Dw
-        out[2 * kFilterPlane + t] = (float)(u * inv_s2 * g / Z - gn * s1);            // Dmu1
-        out[3 * kFilterPlane + t] = (float)(v * inv_s2 * g / Z - gn * s2);            // Dmu2
-        out[4 * kFilterPlane + t] = (float)((u * u + v * v) * inv_s3 * g / Z - gn * s3);  // Dsigma
-        out[5 * kFilterPlane + (k - 1 - j) * k + (k - 1 - i)] = (float)gn;            // Gerr = flip(Gn)
+        out[0 * plane_pitch + t] = (float)gn;                                        // Gn
+        out[1 * plane_pitch + t] = (float)gn;                                        // Dw
+        out[2 * plane_pitch + t] = (float)(u * inv_s2 * g / Z - gn * s1);            // Dmu1
+        out[3 * plane_pitch + t] = (float)(v * inv_s2 * g / Z - gn * s2);            // Dmu2
+        out[4 * plane_pitch + t] = (float)((u * u + v * v) * inv_s3 * g / Z - gn * s3);  // Dsigma
+        out[5 * plane_pitch + (k - 1 - j) * k + (k - 1 - i)] = (float)gn;            // Gerr = flip(Gn)
     }
     // 1-D factors (exact: the masks of single_dim_kernel / forbid_positive_dim1 are separable too)
-    if (lane < k) {
+    if (taps && lane < k) {
         const double t = lane - c;
         double gxs = 0, gys = 0, sx1 = 0, sy1 = 0, sx2 = 0, sy2 = 0;
         for (int q = 0; q < k; ++q) {
@@ -58,7 +59,6 @@ __global__ void synth_filters_kernel(const float* __restrict__ sigma_dev, int k,
         const double gx = ((forbid_pos && t > 0) ? 0.0 : e) / gxs;
         const double gy = ((single_dim && t != 0) ? 0.0 : e) / gys;
         const double m1 = sx1 / gxs, m2 = sy1 / gys, m3 = sx2 / gxs + sy2 / gys;   // = s1, s2, s3 of the 2-D form
-        float* taps = out + kTaps1dOffset;
         taps[kTapGX * kTapPitch + lane] = (float)gx;
         taps[kTapGY * kTapPitch + lane] = (float)gy;
         taps[kTapAX * kTapPitch + lane] = (float)((t * inv_s2 - m1) * gx);
@@ -71,7 +71,14 @@ __global__ void synth_filters_kernel(const float* __restrict__ sigma_dev, int k,
 }
 
 void launch_synth_filters(hipStream_t st, const float* sigma_dev, int k, int flags, float* filters6) {
-    hipLaunchKernelGGL(synth_filters_kernel, dim3(1), dim3(64), 0, st, sigma_dev, k, flags, filters6);
+    hipLaunchKernelGGL(synth_filters_kernel, dim3(1), dim3(64), 0, st, sigma_dev, k, flags, kFilterPlane, filters6,
+                       filters6 + kTaps1dOffset);
+}
+
+// the six planes only, k*k floats each, back to back (dau_conv_filters: the caller's buffer, no scratch)
+void launch_synth_filters_compact(hipStream_t st, const float* sigma_dev, int k, int flags, float* planes6) {
+    hipLaunchKernelGGL(synth_filters_kernel, dim3(1), dim3(64), 0, st, sigma_dev, k, flags, k * k, planes6,
+                       static_cast<float*>(nullptr));
 }
 
 }  // namespace dau

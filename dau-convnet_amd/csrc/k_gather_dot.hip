@@ -62,6 +62,8 @@ struct DotGeometry {
     // The units of a channel are covered by up to two kernel passes: blocks of four units (two unit pairs per wave, two
     // input channels per wave) and, for a remainder of one or two units, one unit pair per wave with four input channels
     // per wave -- every wave carries four (channel, pair) slots either way.  A remainder of three takes a four-unit block.
+    // Several offset windows (R > 8, "binned"): one pass with one SLOT pair per wave and four input channels per wave;
+    // the units of (s, f) that fall into a window are compacted into slots 0, 1, ... of that window, ngb = slot pairs.
     struct Pass { int g_begin, GP, AS, ngb, sblock, nsb, chunks; size_t params_off, params_bytes; };
     int npass;
     Pass pass[2];
@@ -79,6 +81,7 @@ DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one
     DotGeometry g{};
     g.Rt = R < 8 ? R : 8;
     g.nsub1 = R / g.Rt;
+    const bool binned = g.nsub1 > 1;
     g.epitch = kRW + 2 * g.Rt + 1;
     // rows per region: 7 when that pads the height less (7, 14, 21, 27, 28, ...)
     g.RH = ((sh.H + 6) / 7) * 7 < ((sh.H + 7) / 8) * 8 ? 7 : 8;
@@ -94,8 +97,12 @@ DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one
         const int full4 = sh.G / 4, rem = sh.G % 4;
         const int blocks4 = full4 + (rem == 3 ? 1 : 0);
         g.npass = 0;
-        if (blocks4 > 0) g.pass[g.npass++] = DotGeometry::Pass{0, 2, as1 ? 1 : 2, blocks4, 0, 0, 0, 0, 0};
-        if (rem == 1 || rem == 2) g.pass[g.npass++] = DotGeometry::Pass{4 * full4, 1, 4, 1, 0, 0, 0, 0, 0};
+        if (binned) {
+            g.pass[g.npass++] = DotGeometry::Pass{0, 1, 4, (sh.G + 1) / 2, 0, 0, 0, 0, 0};
+        } else {
+            if (blocks4 > 0) g.pass[g.npass++] = DotGeometry::Pass{0, 2, as1 ? 1 : 2, blocks4, 0, 0, 0, 0, 0};
+            if (rem == 1 || rem == 2) g.pass[g.npass++] = DotGeometry::Pass{4 * full4, 1, 4, 1, 0, 0, 0, 0, 0};
+        }
         g.s_pad = 0;
         for (int i = 0; i < g.npass; ++i) {
             DotGeometry::Pass& ps = g.pass[i];
@@ -107,7 +114,7 @@ DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one
         for (int i = 0; i < g.npass; ++i) {
             DotGeometry::Pass& ps = g.pass[i];
             ps.params_off = off;
-            ps.params_bytes = round_up((size_t)g.nsub1 * g.nsub1 * g.s_pad * ps.ngb * ps.GP * g.nfb * 64 * kParamDwords * 4, 256);
+            ps.params_bytes = round_up((size_t)g.nsub1 * g.nsub1 * g.s_pad * ps.ngb * ps.GP * g.nfb * 64 * kParamDwords * 4, 256);   // binned: ngb = slot pairs
             off += ps.params_bytes;
         }
     }
@@ -117,8 +124,11 @@ DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one
     for (int i = 0; i < g.npass; ++i) {
         // at most four full rounds of 256 workgroups (one more workgroup would add a whole, nearly empty round), no
         // more chunks than items, and no chunk without items
-        const int per_chunk = g.nfb * g.pass[i].nsb * g.pass[i].ngb * g.nsub1 * g.nsub1;
-        int chunks = (256 * 4) / per_chunk;
+        // binned: most workgroups beyond the first slot pair find no unit and leave at once; the grid is sized for about
+        // one and a half busy slot pairs per (window, channel block) and eight rounds, so that light and heavy workgroups
+        // even out
+        const int per_chunk = binned ? g.nfb * g.pass[i].nsb * g.nsub1 * g.nsub1 * 3 / 2 : g.nfb * g.pass[i].nsb * g.pass[i].ngb;
+        int chunks = (256 * (binned ? 8 : 4) + (binned ? per_chunk - 1 : 0)) / per_chunk;
         if (chunks > g.items) chunks = g.items;
         if (chunks < 1) chunks = 1;
         const int per = (g.items + chunks - 1) / chunks;
@@ -145,8 +155,9 @@ constexpr int kPackErrorChunk = 512;   // padded columns per workgroup (LDS: 64 
 
 __global__ void __launch_bounds__(256) pack_error_kernel(const float* __restrict__ dy, int N, int F, int H, int W, int R,
                                                          int EX, int EY, int nfb, int drop_col, int drop_row, int bf16,
-                                                         float* __restrict__ ep) {
+                                                         float* __restrict__ ep, const Guard guard) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // [64 = 32 f x 2 images][chunk width | 1]
+    if (!guard_pass(guard)) return;
     const int nxc = (EX + kPackErrorChunk - 1) / kPackErrorChunk;
     int t0 = blockIdx.x;
     const int xc = t0 % nxc; t0 /= nxc;
@@ -191,13 +202,18 @@ struct Blur4Args {
     int ppb, items;             // windows per workgroup (small maps) and windows in total
     unsigned lds_item_floats;   // LDS floats per window
     int WY, WX, nwy, nwx;       // output window (rows x columns of the Hp x Wp plane) and windows per plane
+    Guard guard;
 };
 
 // K: compile-time prefilter support (taps live in SGPRs, tap loops unrolled); K = 0: any support
 template <int K>
 __global__ void __launch_bounds__(512) blur4_pack_kernel(const Blur4Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int C = a.C, H = a.H, W = a.W, k = K ? K : a.k;
+    if (!guard_pass(a.guard)) return;
+    // C counts the channel slots of the staged copy (cstride = input channels padded to whole workgroups of the
+    // gather-dot); slots beyond the real channels are written as zero planes
+    const int C = a.cstride, H = a.H, W = a.W, k = K ? K : a.k;
+    const int Creal = a.C;
     const int lane = threadIdx.x & 63;
     const int nw = (blockDim.x >> 6) / a.ppb;     // waves per window
     const int sub = (threadIdx.x >> 6) / nw, wave = (threadIdx.x >> 6) % nw;
@@ -225,9 +241,12 @@ __global__ void __launch_bounds__(512) blur4_pack_kernel(const Blur4Args a) {
     }
     auto tap = [&](int q, int i) { return K ? tr[q][i] : tp[q][i]; };
     const int n0 = 2 * np, n1 = 2 * np + 1;
-    const long p0 = ((long)n0 * C + c) * H * W, p1 = ((long)(n1 < a.N ? n1 : n0) * C + c) * H * W;   // element offsets
+    const bool real = c < Creal;
+    const int cs = real ? c : 0;
+    const long p0 = ((long)n0 * Creal + cs) * H * W, p1 = ((long)(n1 < a.N ? n1 : n0) * Creal + cs) * H * W;   // element offsets
     const bool bf16 = a.bf16 != 0;
-    const float m1 = n1 < a.N ? 1.0f : 0.0f;
+    const float m0 = real ? 1.0f : 0.0f;
+    const float m1 = (real && n1 < a.N) ? 1.0f : 0.0f;
     // rows x cols of work for this window's waves: a wave per row when the rows are wide, a flat index when they are narrow
     auto for_each = [&](int rows_, int cols_, auto&& body) {
         if (cols_ >= 56) {
@@ -240,7 +259,7 @@ __global__ void __launch_bounds__(512) blur4_pack_kernel(const Blur4Args a) {
     for_each(lh, lw, [&](int r, int xl) {
         const int yy = oy0 - kr + r, xx = ox0 - kr + xl;
         f2 v = {0.0f, 0.0f};
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) { v.x = load_act(a.in, p0 + yy * W + xx, bf16); v.y = m1 * load_act(a.in, p1 + yy * W + xx, bf16); }
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) { v.x = m0 * load_act(a.in, p0 + yy * W + xx, bf16); v.y = m1 * load_act(a.in, p1 + yy * W + xx, bf16); }
         A[r * lw + xl] = v;
     });
     __syncthreads();
@@ -281,7 +300,9 @@ __global__ void __launch_bounds__(512) blur4_pack_kernel(const Blur4Args a) {
 // per-lane parameters: params[sub][s][gb][gp][fb][lane][8] = {b00, b01, b10, b11, base, 0, 0, 0}
 // lane = half*32 + fl ; unit = (s, g = g_begin + gb*2*GP + 2*gp + half, f = fb*32 + fl); invalid units get zero factors.
 __global__ void dot_params_kernel(const UnitRef* __restrict__ table, int S, int G, int F, int R, int Rt, int nsub1,
-                                  int epitch, int g_begin, int GP, int ngb, int nfb, int s_pad, float* __restrict__ params) {
+                                  int epitch, int g_begin, int GP, int ngb, int nfb, int s_pad, float* __restrict__ params,
+                                  const Guard guard) {
+    if (!guard_pass(guard)) return;
     const long total = (long)nsub1 * nsub1 * s_pad * ngb * GP * nfb * 64;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(idx % 64);
@@ -306,15 +327,63 @@ __global__ void dot_params_kernel(const UnitRef* __restrict__ table, int S, int 
     }
 }
 
+// Binned form (several offset windows): params[sub][s][slot pair][fb][lane][8] = {b00, b01, b10, b11, base, g, 0, 0} with
+// lane = (slot & 1)*32 + fl.  The units g of (s, f) whose offsets fall into window `sub` take the slots 0, 1, ... of that
+// window in ascending g; empty slots carry g = -1 and zero factors.  Every unit sits in exactly one (window, slot), so a
+// window pass of the gather-dot visits only its own units (round 1 visited all of them in every window with zeroed
+// factors; the reference splits its large-offset kernels by K instead, dau_conv_backward.cpp:194-231).  Units whose
+// factors are all zero (ignored units) take no slot.  One thread per (window, s, fb, fl).
+__global__ void dot_params_binned_kernel(const UnitRef* __restrict__ table, int S, int G, int F, int R, int Rt, int nsub1,
+                                         int epitch, int nsp, int nfb, int s_pad, float* __restrict__ params,
+                                         const Guard guard) {
+    if (!guard_pass(guard)) return;
+    const long total = (long)nsub1 * nsub1 * s_pad * nfb * kDF;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int fl = (int)(idx % kDF);
+        long t = idx / kDF;
+        const int fb = (int)(t % nfb); t /= nfb;
+        const int s = (int)(t % s_pad);
+        const int sub = (int)(t / s_pad);
+        const int f = fb * kDF + fl;
+        const int cy = -R + Rt + 2 * Rt * (sub / nsub1), cx = -R + Rt + 2 * Rt * (sub % nsub1);
+        auto slot_ptr = [&](int slot) {
+            return params + ((((((long)sub * s_pad + s) * nsp + (slot >> 1)) * nfb + fb) * 64) + (slot & 1) * kDF + fl) * kParamDwords;
+        };
+        int cnt = 0;
+        if (s < S && f < F) {
+            for (int g = 0; g < G; ++g) {
+                const UnitRef u = table[((long)s * G + g) * F + f];
+                int wy = (u.oy + R) / (2 * Rt), wx = (u.ox + R) / (2 * Rt);
+                wy = wy < nsub1 ? wy : nsub1 - 1; wx = wx < nsub1 ? wx : nsub1 - 1;
+                if (wy != sub / nsub1 || wx != sub % nsub1) continue;
+                if (u.w00 == 0.0f && u.w01 == 0.0f && u.w10 == 0.0f && u.w11 == 0.0f) continue;
+                const int base = (((Rt - (u.oy - cy)) * epitch + (Rt - (u.ox - cx))) * kDF + fl) * 8;
+                float* dst = slot_ptr(cnt++);
+                dst[0] = u.w00; dst[1] = u.w01; dst[2] = u.w10; dst[3] = u.w11;
+                dst[4] = __int_as_float(base); dst[5] = __int_as_float(g); dst[6] = 0.0f; dst[7] = 0.0f;
+            }
+        }
+        const int base0 = ((Rt * epitch + Rt) * kDF + fl) * 8;
+        for (; cnt < 2 * nsp; ++cnt) {
+            float* dst = slot_ptr(cnt);
+            dst[0] = 0.0f; dst[1] = 0.0f; dst[2] = 0.0f; dst[3] = 0.0f;
+            dst[4] = __int_as_float(base0); dst[5] = __int_as_float(-1); dst[6] = 0.0f; dst[7] = 0.0f;
+        }
+    }
+}
+
 // r4[k][u] = sum over the slabs of partial[slab][k][u]; units g < g_split were written by a pass with slabs0 slabs,
 // the others by a pass with slabs1 (u = (s*G + g)*F + f)
+// zero_from: units g >= zero_from have no partial sums (binned passes give ignored units no slot): their sums are zero
 __global__ void dot_reduce_kernel(const float* __restrict__ partial, long n, int G, int F, int g_split, int slabs0,
-                                  int slabs1, float* __restrict__ r4) {
+                                  int slabs1, int zero_from, float* __restrict__ r4, const Guard guard) {
+    if (!guard_pass(guard)) return;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int g = (int)((i / F) % G);
         const int slabs = g < g_split ? slabs0 : slabs1;
         double s = 0.0;
-        for (int c = 0; c < slabs; ++c) s += (double)partial[(long)c * n + i];
+        if (g < zero_from)
+            for (int c = 0; c < slabs; ++c) s += (double)partial[(long)c * n + i];
         r4[i] = (float)s;
     }
 }
@@ -334,6 +403,7 @@ struct DotArgs {
     int rx, ry, EX, EY, Hp, Wp, epitch, erows, s_pad;
     unsigned tile_bytes;
     int debug;   // timing experiments only (DAU_DOT_DEBUG): 1 = Xk always from one address, 2 = no error-tile refills
+    Guard guard;
 };
 
 // Packed fp32 helpers.  Plain vector builtins (not inline asm): hipcc selects v_pk_mul_f32 / v_pk_fma_f32,
@@ -380,11 +450,14 @@ __device__ __forceinline__ f4 mfma_bcast(float a, float b, f4 c, int abid) {
 
 // RH rows per region; the Xk ring has one slot per two region rows = 16 positions (the last slot of an odd RH fetches one
 // row too many, which is never used; the buffer has a spare row at its end)
-template <int GP, int AS, int RH>
+// BINNED: window pass over compacted unit slots (dot_params_binned_kernel): a lane's unit index comes with its
+// parameters, input channels whose slots are all empty are skipped by the wave, and a workgroup without any unit leaves.
+template <int GP, int AS, int RH, bool BINNED = false>
 __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) gather_dot_kernel(const DotArgs a) {
     constexpr int kRH = RH;
     constexpr int kXSlots = (RH + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (!guard_pass(a.guard)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
@@ -414,19 +487,39 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     // per-lane parameters of the wave's AS x GP units, resident in registers for the whole kernel
     f2 bw[AS][GP][2];
     unsigned base[AS][GP];
+    int gidx[AS][GP];           // BINNED: the lane's unit g, -1 for an empty slot
     int s_of[AS];
+    bool act[AS];               // BINNED: some lane of the wave has a unit of input channel si (wave-uniform)
+    const int s_base = sb * (kDWaves * AS) + wave * AS;
 #pragma unroll
     for (int si = 0; si < AS; ++si) {
-        const int s = sb * (kDWaves * AS) + wave * AS + si;
+        const int s = s_base + si;
         s_of[si] = s;
+        act[si] = true;
 #pragma unroll
         for (int gp = 0; gp < GP; ++gp) {
             const float* p = a.params + ((((((long)sub * a.s_pad + s) * a.ngb + gb) * GP + gp) * a.nfb + fb) * 64 + lane) * kParamDwords;
             bw[si][gp][0] = f2{p[0], p[1]};
             bw[si][gp][1] = f2{p[2], p[3]};
             base[si][gp] = (unsigned)__float_as_int(p[4]);
+            gidx[si][gp] = BINNED ? __float_as_int(p[5]) : 0;
+        }
+        if constexpr (BINNED) {
+            bool any = false;
+#pragma unroll
+            for (int gp = 0; gp < GP; ++gp) any = any || gidx[si][gp] >= 0;
+            act[si] = __ballot(any) != 0ull;
         }
     }
+    int first_act = 0;          // first input channel of the wave that has units; AS: none
+    if constexpr (BINNED) {
+        first_act = AS;
+#pragma unroll
+        for (int si = AS - 1; si >= 0; --si) first_act = act[si] ? si : first_act;
+        // this slot pair is empty for the whole (window, channel block, 64 input channels): nothing to do
+        if (!__syncthreads_or(first_act < AS ? 1 : 0)) return;
+    }
+    const bool wave_idle = first_act >= AS;
 
     f4 acc[AS][GP][2];   // [input channel][unit pair][image]: register k = gradient kind
 #pragma unroll
@@ -502,9 +595,11 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     for (int i = 0; i < kXSlots; ++i) xr[i] = f2{0.0f, 0.0f};
     if (item0 < item1) {
         issue(item0, 0);
-        const char* x0 = sweep_ptr(item0, s_of[0]);
+        if (!wave_idle) {
+            const char* x0 = sweep_ptr(item0, s_base + first_act);
 #pragma unroll
-        for (int i = 0; i < kXSlots; ++i) x_load(xr[i], xlane, x0 + 2 * i * xpitch, 0);
+            for (int i = 0; i < kXSlots; ++i) x_load(xr[i], xlane, x0 + 2 * i * xpitch, 0);
+        }
     }
     for (int item = item0; item < item1; ++item) {
         const bool two = a.nbuf == 2;
@@ -523,11 +618,16 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
         const unsigned bufoff = buf * tile_bytes;
 #pragma unroll
         for (int si = 0; si < AS; ++si) {
+            if (BINNED && !act[si]) continue;     // wave-uniform: no unit of this input channel in the wave's slots
             const char* xbase = sweep_ptr(item, s_of[si]);
-            // where the ring continues after this sweep: next input channel of this item, or the next item
-            // (or, at the very end, the last row again so that the number of loads in flight stays constant)
-            const char* xnext_sweep = si + 1 < AS ? sweep_ptr(item, s_of[si + 1 < AS ? si + 1 : si])
-                                                  : (item + 1 < item1 ? sweep_ptr(item + 1, s_of[0]) : xbase);
+            // where the ring continues after this sweep: next input channel of this item (BINNED: the next one that
+            // has units), or the next item (or, at the very end, the last row again so that the number of loads in
+            // flight stays constant)
+            int nxt = AS;
+#pragma unroll
+            for (int sj = AS - 1; sj > si; --sj) nxt = act[sj] ? sj : nxt;
+            const char* xnext_sweep = nxt < AS ? sweep_ptr(item, s_base + nxt)
+                                               : (item + 1 < item1 ? sweep_ptr(item + 1, s_base + first_act) : xbase);
 
             // The sweep over the 8x8 region is fully unrolled (no back-edge copies).  Software pipeline over groups
             // of two positions: at the END of a group one lgkmcnt(0) retires the error columns prefetched for the
@@ -637,7 +737,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                     { DAU_PREFETCH_COL(GS - 1) }
                     // Xk of this row pair: its slot is the oldest of the ring
                     if (j % 2 == 0 && gq == 0) {
-                        if (si == 0 && two) x_wait<kXSlots - 1 + kRounds4>();
+                        if (!BINNED && si == 0 && two) x_wait<kXSlots - 1 + kRounds4>();
                         else x_wait<kXSlots - 1>();
                     }
 #pragma unroll
@@ -666,16 +766,17 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // partial[chunk][k][(s*G+g)*F+f] = image 0 + image 1
+    // partial[chunk][k][(s*G+g)*F+f] = image 0 + image 1.  Every unit is written by exactly one workgroup per chunk:
+    // its own (unit block) pass, or -- BINNED -- the pass of the one (window, slot) it was binned into.
     const long units = (long)a.S * a.G * a.F;
     const int half = lane >> 5, f = fb * kDF + (lane & 31);
 #pragma unroll
     for (int si = 0; si < AS; ++si)
 #pragma unroll
         for (int gp = 0; gp < GP; ++gp) {
-            const int s = s_of[si], g = a.g_begin + gb * 2 * GP + 2 * gp + half;
-            if (s < a.S && g < a.G && f < a.F) {
-                float* dst = a.partial + ((long)chunk * nsub + sub) * kNumK * units + ((long)s * a.G + g) * a.F + f;
+            const int s = s_of[si], g = BINNED ? gidx[si][gp] : a.g_begin + gb * 2 * GP + 2 * gp + half;
+            if (s < a.S && g >= 0 && g < a.G && f < a.F) {
+                float* dst = a.partial + (long)chunk * kNumK * units + ((long)s * a.G + g) * a.F + f;
 #pragma unroll
                 for (int kk = 0; kk < kNumK; ++kk) dst[kk * units] = acc[si][gp][0][kk] + acc[si][gp][1][kk];
             }
@@ -698,10 +799,9 @@ DotLayout dot_layout(const TiledDotConfig& c, const DotGeometry& g) {
     size_t off = 0;
     l.ep_off = off; off += round_up(NP * g.nfb * g.EY * g.EX * kDF * 8, 256);
     l.xk_off = off; off += round_up(NP * s_pad * g.Hp * g.Wp * 32 + (size_t)g.Wp * 32, 256);   // + one spare row
-    const size_t nsub = (size_t)g.nsub1 * g.nsub1;
     l.params_off = off;
     for (int i = 0; i < g.npass; ++i) off += g.pass[i].params_bytes;
-    l.partial_off = off; off += round_up(nsub * g.chunks * kNumK * c.sh.S * c.sh.G * c.sh.F * 4, 256);
+    l.partial_off = off; off += round_up((size_t)g.chunks * kNumK * c.sh.S * c.sh.G * c.sh.F * 4, 256);
     l.total = off;
     return l;
 }
@@ -716,16 +816,36 @@ void blur4_plan(int k, int Hp, int Wp, int* wy, int* wx, size_t* lds) {
     *wy = WY; *wx = WX; *lds = bytes(WY);
 }
 
-template <int GP, int AS, int RH>
-void launch_dot(hipStream_t st, const DotArgs& a, int grid, size_t lds) {
-    auto kern = gather_dot_kernel<GP, AS, RH>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kDWaves * 64), lds, st, a);
+// a == nullptr: raise the kernel's dynamic-LDS limit (once per plan and device, tiled_dot_init); else launch
+template <int GP, int AS, int RH, bool BINNED = false>
+void launch_dot(hipStream_t st, const DotArgs* a, int grid, size_t lds) {
+    auto kern = gather_dot_kernel<GP, AS, RH, BINNED>;
+    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return; }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kDWaves * 64), lds, st, *a);
+}
+
+void dispatch_dot(bool binned, int RH, int GP, int AS, hipStream_t st, const DotArgs* a, int grid, size_t lds) {
+    if (binned) {
+        if (RH == 8) launch_dot<1, 4, 8, true>(st, a, grid, lds);
+        else launch_dot<1, 4, 7, true>(st, a, grid, lds);
+    } else if (RH == 8) {
+        if (GP == 1) launch_dot<1, 4, 8>(st, a, grid, lds);
+        else if (AS == 2) launch_dot<2, 2, 8>(st, a, grid, lds);
+        else launch_dot<2, 1, 8>(st, a, grid, lds);
+    } else {
+        if (GP == 1) launch_dot<1, 4, 7>(st, a, grid, lds);
+        else if (AS == 2) launch_dot<2, 2, 7>(st, a, grid, lds);
+        else launch_dot<2, 1, 7>(st, a, grid, lds);
+    }
+}
+
+auto blur4_pack_for(int blur_k) {
+    return blur_k == 7 ? blur4_pack_kernel<7> : blur_k == 5 ? blur4_pack_kernel<5> : blur_k == 9 ? blur4_pack_kernel<9> : blur4_pack_kernel<0>;
 }
 
 }  // namespace
 
-bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, TiledDotConfig* cfg) {
+bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, int ignore, TiledDotConfig* cfg) {
     // timing experiments: DAU_DOT_AS1 (one input channel per wave), DAU_DOT_NBUF=1 (one error tile), DAU_DOT_DEBUG
     const bool as1 = getenv("DAU_DOT_AS1") != nullptr;
     const bool one_tile = getenv("DAU_DOT_NBUF") && atoi(getenv("DAU_DOT_NBUF")) == 1;
@@ -740,7 +860,7 @@ bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, TiledDot
     }
     TiledDotConfig c{};
     c.sh = sh; c.R = R; c.blur_k = blur_k; c.NP = (sh.N + 1) / 2; c.variant = g.npass; c.windows = g.nsub1 * g.nsub1;
-    c.bf16 = bf16;
+    c.bf16 = bf16; c.ignore = ignore;
     c.as1 = as1; c.one_tile = one_tile; c.debug = getenv("DAU_DOT_DEBUG") ? atoi(getenv("DAU_DOT_DEBUG")) : 0;
     *cfg = c;
     return true;
@@ -750,8 +870,15 @@ size_t tiled_dot_workspace_bytes(const TiledDotConfig& c) {
     return dot_layout(c, make_dot_geometry(c.sh, c.R, c.as1, c.one_tile)).total;
 }
 
+void tiled_dot_init(const TiledDotConfig& c) {
+    const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile);
+    for (int i = 0; i < g.npass; ++i) dispatch_dot(g.nsub1 > 1, g.RH, g.pass[i].GP, g.pass[i].AS, nullptr, nullptr, 0, 0);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pack_error_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blur4_pack_for(c.blur_k)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, const float* dy, const float* filters,
-                       const UnitRef* table_bare, int drop_col, int drop_row, void* workspace) {
+                       const UnitRef* table_bare, int drop_col, int drop_row, void* workspace, const Guard& guard) {
     const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile);
     const DotLayout l = dot_layout(c, g);
     char* ws = static_cast<char*>(workspace);
@@ -761,18 +888,16 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
         const int cwmax = s.W < kPackErrorChunk ? s.W : kPackErrorChunk;
         const size_t lds = (size_t)64 * (cwmax | 1) * 4;
         const int nxc = (g.EX + kPackErrorChunk - 1) / kPackErrorChunk;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pack_error_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(pack_error_kernel, dim3(c.NP * g.nfb * g.EY * nxc), dim3(256), lds, st, dy, s.N, s.F, s.H, s.W, c.R, g.EX,
-                           g.EY, g.nfb, drop_col, drop_row, c.bf16 ? 1 : 0, reinterpret_cast<float*>(ws + l.ep_off));
+                           g.EY, g.nfb, drop_col, drop_row, c.bf16 ? 1 : 0, reinterpret_cast<float*>(ws + l.ep_off), guard);
     }
     {
-        // channels beyond S (padding of the last input-channel block) must read as zero
-        if (s_pad != s.S) (void)hipMemsetAsync(ws + l.xk_off, 0, (size_t)c.NP * s_pad * g.Hp * g.Wp * 32, st);
+        // channel slots beyond S (padding of the last input-channel block) are written as zero planes by the kernel
         int wy, wx; size_t blur_lds;
         blur4_plan(c.blur_k, g.Hp, g.Wp, &wy, &wx, &blur_lds);
-        auto kern = c.blur_k == 7 ? blur4_pack_kernel<7> : c.blur_k == 5 ? blur4_pack_kernel<5> : c.blur_k == 9 ? blur4_pack_kernel<9> : blur4_pack_kernel<0>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        auto kern = blur4_pack_for(c.blur_k);
         Blur4Args b{};
+        b.guard = guard;
         b.in = x; b.taps = filters + kTaps1dOffset; b.xk = reinterpret_cast<float*>(ws + l.xk_off);
         b.N = s.N; b.C = s.S; b.cstride = s_pad; b.H = s.H; b.W = s.W; b.k = c.blur_k; b.Hp = g.Hp; b.Wp = g.Wp; b.bf16 = c.bf16 ? 1 : 0;
         b.WY = wy; b.WX = wx; b.nwy = (g.Hp + wy - 1) / wy; b.nwx = (g.Wp + wx - 1) / wx;
@@ -780,9 +905,17 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
         const int elems = wy * wx;
         b.ppb = elems >= 2048 ? 1 : elems >= 1024 ? 2 : elems >= 512 ? 4 : 8;
         while (b.ppb > 1 && b.ppb * blur_lds > 64 * 1024) b.ppb /= 2;
-        b.items = c.NP * b.nwy * b.nwx * s.S;
+        b.items = c.NP * b.nwy * b.nwx * s_pad;
         b.lds_item_floats = (unsigned)(blur_lds / 4);
         hipLaunchKernelGGL(kern, dim3((b.items + b.ppb - 1) / b.ppb), dim3(512), b.ppb * blur_lds, st, b);
+    }
+    if (g.nsub1 > 1) {
+        const DotGeometry::Pass& ps = g.pass[0];
+        const long total = (long)g.nsub1 * g.nsub1 * s_pad * g.nfb * kDF;
+        const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(dot_params_binned_kernel, dim3(grid), dim3(256), 0, st, table_bare, s.S, s.G, s.F, c.R, g.Rt, g.nsub1,
+                           g.epitch, ps.ngb, g.nfb, s_pad, reinterpret_cast<float*>(ws + l.params_off + ps.params_off), guard);
+        return;
     }
     for (int i = 0; i < g.npass; ++i) {
         const DotGeometry::Pass& ps = g.pass[i];
@@ -790,11 +923,11 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
         const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         hipLaunchKernelGGL(dot_params_kernel, dim3(grid), dim3(256), 0, st, table_bare, s.S, s.G, s.F, c.R, g.Rt, g.nsub1,
                            g.epitch, ps.g_begin, ps.GP, ps.ngb, g.nfb, s_pad,
-                           reinterpret_cast<float*>(ws + l.params_off + ps.params_off));
+                           reinterpret_cast<float*>(ws + l.params_off + ps.params_off), guard);
     }
 }
 
-void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* workspace) {
+void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* workspace, const Guard& guard) {
     const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile);
     const DotLayout l = dot_layout(c, g);
     char* ws = static_cast<char*>(workspace);
@@ -809,28 +942,21 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
     a.s_pad = g.s_pad;
     a.tile_bytes = (unsigned)g.tile_bytes;
     a.debug = c.debug;
+    a.guard = guard;
+    const bool binned = g.nsub1 > 1;
     const size_t lds = (size_t)g.nbuf * g.tile_bytes;
     for (int i = 0; i < g.npass; ++i) {           // every pass writes its own units' slabs of the partial sums
         const DotGeometry::Pass& ps = g.pass[i];
         a.params = reinterpret_cast<const float*>(ws + l.params_off + ps.params_off);
         a.g_begin = ps.g_begin; a.nsb = ps.nsb; a.ngb = ps.ngb; a.chunks = ps.chunks;
         const int grid = ps.chunks * g.nsub1 * g.nsub1 * g.nfb * ps.ngb * ps.nsb;
-        if (g.RH == 8) {
-            if (ps.GP == 1) launch_dot<1, 4, 8>(st, a, grid, lds);
-            else if (ps.AS == 2) launch_dot<2, 2, 8>(st, a, grid, lds);
-            else launch_dot<2, 1, 8>(st, a, grid, lds);
-        } else {
-            if (ps.GP == 1) launch_dot<1, 4, 7>(st, a, grid, lds);
-            else if (ps.AS == 2) launch_dot<2, 2, 7>(st, a, grid, lds);
-            else launch_dot<2, 1, 7>(st, a, grid, lds);
-        }
+        dispatch_dot(binned, g.RH, ps.GP, ps.AS, st, &a, grid, lds);
     }
     const long n = (long)kNumK * s.S * s.G * s.F;
     const int rgrid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    const int nsub = g.nsub1 * g.nsub1;
     const int g_split = g.npass == 2 ? g.pass[1].g_begin : s.G;
     hipLaunchKernelGGL(dot_reduce_kernel, dim3(rgrid), dim3(256), 0, st, a.partial, n, s.G, s.F, g_split,
-                       g.pass[0].chunks * nsub, g.pass[g.npass - 1].chunks * nsub, r4);
+                       g.pass[0].chunks, g.pass[g.npass - 1].chunks, binned ? s.G - c.ignore : s.G, r4, guard);
 }
 
 }  // namespace dau

@@ -48,9 +48,10 @@ inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // image are computed and dropped at the store); the one non-EDGE variant covers a whole 25..31 pixel image.
 struct Geometry {
     int H, W, R;              // image, offset bucket
-    int Rt;                   // offset radius one staged plane covers: min(R, 16)
-    int nwin1;                // R = 32: the offset range is cut into nwin1 x nwin1 windows of radius Rt, one gather pass per
-                              // window (shifted planes, units outside the window carry zero weights), outputs accumulate
+    int Rt;                   // offset radius one staged plane covers: R for R <= 16, R/2 for R = 24, 32
+    int nwin1;                // R > 16: the offset range is cut into nwin1 x nwin1 windows of radius Rt, one gather pass per
+                              // window (shifted planes; the units are binned by window, a pass gathers only its own),
+                              // outputs accumulate
     int ph, pw;               // patch (pixels)
     int npx, npy;             // patches per image
     int rows, pitch, cols;    // staged plane of one patch: rows x pitch positions, the first `cols` columns carry data
@@ -88,14 +89,17 @@ const Variant kVariants[] = {
     {1, 1, 40, 0, 1, 8, 5120, 16, 0},   // 15: 8 x one <=7 pixel image (7x7), 16 channels
 };
 
-size_t ut_stride_bytes(int G, int fb) { return round_up((size_t)G * fb * kUnitDwords * 4, 1024); }
+// one (channel block, input channel) slice of the packed unit table: [G slots][fb channels][8 dwords]; window passes
+// (binned) append the number of slots each channel uses in this pass: [fb] dwords
+size_t ut_stride_bytes(int G, int fb, bool binned) { return round_up((size_t)G * fb * kUnitDwords * 4 + (binned ? fb * 4 : 0), 1024); }
 
 // N, Cout only steer the choice between stacked and plain variants (enough workgroups to fill the chip)
 // only: >= 0 pins the row of kVariants (the plan's choice, so that every later call sees the same layout)
 Geometry make_geometry(int H, int W, int R, int G, int N, int Cout, int only = -1) {
     Geometry g{};
     g.H = H; g.W = W; g.R = R; g.variant = -1;
-    g.Rt = R > 16 ? 16 : R; g.nwin1 = R / g.Rt;
+    g.nwin1 = (R + 15) / 16; g.Rt = R / g.nwin1;
+    const bool binned = g.nwin1 > 1;
     R = g.Rt;                                                // everything below sizes ONE plane
     // The environment is consulted at plan creation only (only < 0); afterwards the plan's row is passed in.
     //   DAU_GATHER_VARIANT=<row>  pins the kernel (tests of the small-map variants on small batches)
@@ -126,7 +130,7 @@ Geometry make_geometry(int H, int W, int R, int G, int N, int Cout, int only = -
         const size_t plane = round_up(((size_t)rows * v.pitch + (v.edge ? (size_t)(2 * R + 1) * rows : 0)) * 8, 1024);
         if (v.plane_bytes && plane != (size_t)v.plane_bytes) continue;
         // two buffers of sk planes + two unit slices must fit the 160 KiB of LDS
-        if (2 * v.sk * plane + 2 * ut_stride_bytes(G, v.fb) > 160 * 1024) continue;
+        if (2 * v.sk * plane + 2 * ut_stride_bytes(G, v.fb, binned) > 160 * 1024) continue;
         const int npx = (W + pw - 1) / pw, npy = (H + ph - 1) / ph;
         const long planes = (long)((N + 1) / 2) * npx * npy, groups = (planes + v.sk - 1) / v.sk;
         if (never_stack && v.sk > 1) continue;
@@ -174,12 +178,14 @@ struct BlurPackArgs {
                                 // workgroups per CU to hide the memory latency of this HBM-bound kernel)
     int planes;                 // (image pair, patch, channel, band) work items in total
     unsigned lds_plane_floats;  // LDS floats per plane
+    Guard guard;
 };
 
 // K: compile-time prefilter support (taps live in SGPRs, tap loops unrolled); K = 0: any support, taps re-read per use
 template <int K>
 __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (!guard_pass(a.guard)) return;
     const int C = a.C, H = a.H, W = a.W, R = a.R, k = K ? K : a.k;
     const int lane = threadIdx.x & 63;
     const int nw = (blockDim.x >> 6) / a.ppb;     // waves per plane
@@ -266,7 +272,8 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
 // R: offset bucket; Rt, nwin1, window: the pass's offset window (Rt == R, nwin1 == 1: the whole bucket)
 __global__ void pack_units_kernel(const UnitRef* __restrict__ table, int Cin, int G, int Cout, int pitch, int R, int Rt,
                                   int nwin1, int window, int strip_pitch, int ut_stride_dwords, int kFB,
-                                  unsigned int* __restrict__ packed) {
+                                  unsigned int* __restrict__ packed, const Guard guard) {
+    if (!guard_pass(guard)) return;
     const int nfb = (Cout + kFB - 1) / kFB;
     const long total = (long)nfb * Cin * G * kFB;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -293,6 +300,47 @@ __global__ void pack_units_kernel(const UnitRef* __restrict__ table, int Cin, in
     }
 }
 
+// Window passes (R > 16): the units of (input channel c, output channel f) that fall into this pass's offset window are
+// compacted into the first slots of the slice and their number goes into the slice's count word, so that the gather
+// visits only them (the reference splits the work of its large-offset kernels by K instead, dau_conv_backward.cpp:194-231;
+// round 1 here visited every unit in every window with zeroed weights).  Units whose four weights are all zero (ignored
+// units, number_units_ignore) are dropped.  One thread per (channel block, c, channel of the block).
+__global__ void pack_units_binned_kernel(const UnitRef* __restrict__ table, int Cin, int G, int Cout, int pitch, int R,
+                                         int Rt, int nwin1, int window, int strip_pitch, int ut_stride_dwords, int kFB,
+                                         unsigned int* __restrict__ packed, const Guard guard) {
+    if (!guard_pass(guard)) return;
+    const int nfb = (Cout + kFB - 1) / kFB;
+    const long total = (long)nfb * Cin * kFB;
+    const int cy = -R + Rt + 2 * Rt * (window / nwin1), cx = -R + Rt + 2 * Rt * (window % nwin1);
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int fi = (int)(idx % kFB);
+        const int c = (int)((idx / kFB) % Cin);
+        const int fb = (int)(idx / ((long)kFB * Cin));
+        const int f = fb * kFB + fi;
+        unsigned int* slice = packed + ((long)fb * Cin + c) * ut_stride_dwords;
+        int cnt = 0;
+        if (f < Cout) {
+            for (int g = 0; g < G; ++g) {
+                const UnitRef u = table[((long)c * G + g) * Cout + f];
+                int wy = (u.oy + R) / (2 * Rt), wx = (u.ox + R) / (2 * Rt);
+                wy = wy < nwin1 ? wy : nwin1 - 1; wx = wx < nwin1 ? wx : nwin1 - 1;
+                if (wy != window / nwin1 || wx != window % nwin1) continue;
+                if (u.w00 == 0.0f && u.w01 == 0.0f && u.w10 == 0.0f && u.w11 == 0.0f) continue;
+                const int ox = u.ox - cx, oy = u.oy - cy;    // displacement relative to the window centre, |.| <= Rt
+                const int off = (oy * pitch + ox) * 8;
+                const int offt = ((ox + Rt) * strip_pitch + oy) * 8;
+                unsigned int* dst = slice + (cnt * kFB + fi) * kUnitDwords;
+                dst[0] = __float_as_uint(u.w00); dst[1] = (unsigned)off;
+                dst[2] = __float_as_uint(u.w01); dst[3] = (unsigned)off;
+                dst[4] = __float_as_uint(u.w10); dst[5] = (unsigned)offt;
+                dst[6] = __float_as_uint(u.w11); dst[7] = (unsigned)offt;
+                ++cnt;
+            }
+        }
+        slice[G * kFB * kUnitDwords + fi] = (unsigned)cnt;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // main kernel
 // ------------------------------------------------------------------------------------------------
@@ -309,6 +357,8 @@ struct GatherArgs {
     int accumulate;            // 1: add to out (second and later offset-window passes)
     int bf16;                  // out is bfloat16 (DAU_FLAG_IO_BF16)
     int debug;                 // timing experiments only (DAU_GATHER_DEBUG): 1 = no plane refills after the first two
+    int binned;                // window pass: every channel's slot count comes from its slice's count words
+    Guard guard;
 };
 
 // TX, TY : regular 8x8 tiles of one plane;  PITCH: staged pitch (positions);  EDGE: two extra edge tiles per plane
@@ -528,14 +578,22 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
         const unsigned pbase = buf * buf_bytes;
         const unsigned ut_addr = ut_base + buf * ut_stride + (fi * kUnitDwords + (lane & 3) * 2) * 4;
         constexpr unsigned unit_pitch = T::FB * kUnitDwords * 4;
+        // slots this wave's output channel uses in this input channel: all G, or (window pass) the slice's count word
+        int ng = a.G;
+        if (a.binned) {
+            unsigned cw;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)"
+                         : "=v"(cw) : "v"(ut_base + buf * ut_stride + (unsigned)(a.G * T::FB * kUnitDwords + fi) * 4) : "memory");
+            ng = __builtin_amdgcn_readfirstlane((int)cw);
+        }
         int g = 0;
-        for (; g + 4 <= a.G; g += 4)
+        for (; g + 4 <= ng; g += 4)
             unit_group<T, PART, KP, 4>(acc, ut_addr + g * unit_pitch, unit_pitch, pbase, lane_base, ebase0, ebase1);
-        if (g + 2 <= a.G) {
+        if (g + 2 <= ng) {
             unit_group<T, PART, KP, 2>(acc, ut_addr + g * unit_pitch, unit_pitch, pbase, lane_base, ebase0, ebase1);
             g += 2;
         }
-        if (g < a.G)
+        if (g < ng)
             unit_group<T, PART, KP, 1>(acc, ut_addr + g * unit_pitch, unit_pitch, pbase, lane_base, ebase0, ebase1);
     }
 
@@ -591,6 +649,7 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
 template <class T>
 __global__ void __launch_bounds__(T::kThreads) gather_mfma_kernel(const GatherArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (!guard_pass(a.guard)) return;
     constexpr int SPLIT = T::SPLIT;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -606,11 +665,39 @@ __global__ void __launch_bounds__(T::kThreads) gather_mfma_kernel(const GatherAr
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+// a == nullptr: raise the kernel's dynamic-LDS limit (once per plan and device, tiled_gather_init); else launch
 template <class T>
-void launch_variant(hipStream_t st, const GatherArgs& a, int grid, size_t lds) {
+void launch_variant(hipStream_t st, const GatherArgs* a, int grid, size_t lds) {
     auto kern = gather_mfma_kernel<T>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::kThreads), lds, st, a);
+    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return; }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T::kThreads), lds, st, *a);
+}
+
+void dispatch_variant(int variant, hipStream_t st, const GatherArgs* a, int grid, size_t lds) {
+    switch (variant) {
+        case 0: launch_variant<GatherTraits<7, 7, 72, true, 2>>(st, a, grid, lds); break;
+        case 1: launch_variant<GatherTraits<7, 7, 104, true, 2>>(st, a, grid, lds); break;
+        case 2: launch_variant<GatherTraits<4, 4, 72, true, 1>>(st, a, grid, lds); break;
+        case 3: launch_variant<GatherTraits<2, 2, 40, true, 1>>(st, a, grid, lds); break;
+        case 4: launch_variant<GatherTraits<3, 3, 40, true, 1>>(st, a, grid, lds); break;
+        case 5: launch_variant<GatherTraits<1, 1, 40, true, 1>>(st, a, grid, lds); break;
+        case 6: launch_variant<GatherTraits<4, 4, 40, false, 1>>(st, a, grid, lds); break;
+        case 7: launch_variant<GatherTraits<7, 7, 72, true, 3>>(st, a, grid, lds); break;
+        case 8: launch_variant<GatherTraits<4, 4, 72, true, 2, 2, 26624>>(st, a, grid, lds); break;
+        case 9: launch_variant<GatherTraits<3, 3, 40, true, 2, 4, 13312>>(st, a, grid, lds); break;
+        case 10: launch_variant<GatherTraits<2, 2, 40, true, 1, 4, 10240, 8>>(st, a, grid, lds); break;
+        case 11: launch_variant<GatherTraits<1, 1, 40, true, 1, 4, 7168, 16>>(st, a, grid, lds); break;
+        case 12: launch_variant<GatherTraits<4, 4, 40, false, 2, 3, 13312>>(st, a, grid, lds); break;
+        case 13: launch_variant<GatherTraits<3, 3, 40, false, 1, 2, 10240, 8>>(st, a, grid, lds); break;
+        case 14: launch_variant<GatherTraits<2, 2, 40, false, 1, 4, 8192, 8>>(st, a, grid, lds); break;
+        case 15: launch_variant<GatherTraits<1, 1, 40, false, 1, 8, 5120, 16>>(st, a, grid, lds); break;
+        default: break;
+    }
+}
+
+auto blur_pack_for(int blur_k) {
+    // sigma = 0.5 (the reference's default) gives a 7-tap prefilter; other supports take the generic instantiation
+    return blur_k == 7 ? blur_pack_kernel<7> : blur_k == 5 ? blur_pack_kernel<5> : blur_k == 9 ? blur_pack_kernel<9> : blur_pack_kernel<0>;
 }
 
 // largest window any patch (band of band_rows staged rows) needs: raw [lh][lw] + horizontally filtered [lh][bw]
@@ -628,7 +715,7 @@ int blur_pack_bands(const Geometry& g, int k) {
 }
 
 size_t lds_bytes(const TiledConfig& c, const Geometry& g) {
-    const size_t main_b = 2 * g.sk * g.plane_bytes + 2 * ut_stride_bytes(c.G, g.fb);
+    const size_t main_b = 2 * g.sk * g.plane_bytes + 2 * ut_stride_bytes(c.G, g.fb, g.nwin1 > 1);
     const size_t zpitch = g.pw + 2;
     const size_t epi_b = (size_t)g.sk * 2 /*kEpiF*/ * 4 * (g.ph + 1) * zpitch * 4;
     return main_b > epi_b ? main_b : epi_b;
@@ -656,23 +743,27 @@ bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R
 size_t tiled_gather_workspace_bytes(const TiledConfig& c) {
     const Geometry g = make_geometry(c.H, c.W, c.R, c.G, c.N, c.Cout, c.variant);
     const size_t nfb = (c.Cout + g.fb - 1) / g.fb;
-    return round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256) + round_up(nfb * c.Cin * ut_stride_bytes(c.G, g.fb), 256);
+    return round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256) + round_up(nfb * c.Cin * ut_stride_bytes(c.G, g.fb, g.nwin1 > 1), 256);
+}
+
+void tiled_gather_init(const TiledConfig& c) {
+    dispatch_variant(c.variant, nullptr, nullptr, 0, 0);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blur_pack_for(c.blur_k)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 int tiled_gather_windows(const TiledConfig& c) { return c.windows; }
 
 void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in, const float* filters, bool mirrored,
-                          const UnitRef* table, void* workspace, int window) {
+                          const UnitRef* table, void* workspace, int window, const Guard& guard) {
     const Geometry g = make_geometry(c.H, c.W, c.R, c.G, c.N, c.Cout, c.variant);
     char* staged = static_cast<char*>(workspace);
     char* packed = staged + round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256);
     const int bands = blur_pack_bands(g, c.blur_k);
     const int band_rows = (g.rows + bands - 1) / bands;
     const size_t blur_lds = blur_pack_lds_bytes(g, c.blur_k, band_rows);
-    // sigma = 0.5 (the reference's default) gives a 7-tap prefilter; other supports take the generic instantiation
-    auto kern = c.blur_k == 7 ? blur_pack_kernel<7> : c.blur_k == 5 ? blur_pack_kernel<5> : c.blur_k == 9 ? blur_pack_kernel<9> : blur_pack_kernel<0>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    auto kern = blur_pack_for(c.blur_k);
     BlurPackArgs b{};
+    b.guard = guard;
     b.in = in; b.taps = filters + kTaps1dOffset; b.staged = reinterpret_cast<float*>(staged);
     // centre of this pass's offset window: staged (row, col) of a patch is the image at (py*ph - Rt + cy + row, ...)
     const int cy = -c.R + g.Rt + 2 * g.Rt * (window / g.nwin1), cx = -c.R + g.Rt + 2 * g.Rt * (window % g.nwin1);
@@ -691,18 +782,28 @@ void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in,
     b.lds_plane_floats = (unsigned)(blur_lds / 4);
     hipLaunchKernelGGL(kern, dim3((b.planes + b.ppb - 1) / b.ppb), dim3(512), b.ppb * blur_lds, st, b);
     const int nfb = (c.Cout + g.fb - 1) / g.fb;
-    const size_t uts = ut_stride_bytes(c.G, g.fb);
-    // packed slices are padded to whole KiB; zero the padding once per call together with the payload
+    const bool binned = g.nwin1 > 1;
+    const size_t uts = ut_stride_bytes(c.G, g.fb, binned);
+    if (binned) {
+        // slots beyond a channel's count and the KiB padding are never read
+        const long total = (long)nfb * c.Cin * g.fb;
+        const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+        hipLaunchKernelGGL(pack_units_binned_kernel, dim3(grid), dim3(256), 0, st, table, c.Cin, c.G, c.Cout, g.pitch, c.R, g.Rt,
+                           g.nwin1, window, g.strip_pitch, (int)(uts / 4), g.fb, reinterpret_cast<unsigned int*>(packed), guard);
+        return;
+    }
+    // Packed slices are padded to whole KiB; the padding is zeroed together with the payload.  The memset is not guarded:
+    // the candidate bucket sets of a call run one after the other in the same workspace, so it is harmless for the other.
     (void)hipMemsetAsync(packed, 0, (size_t)nfb * c.Cin * uts, st);
     const long total = (long)nfb * c.Cin * c.G * g.fb;
     const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
     hipLaunchKernelGGL(pack_units_kernel, dim3(grid), dim3(256), 0, st, table, c.Cin, c.G, c.Cout, g.pitch, c.R, g.Rt, g.nwin1,
                        window, g.strip_pitch,
                        (int)(uts / 4), g.fb,
-                       reinterpret_cast<unsigned int*>(packed));
+                       reinterpret_cast<unsigned int*>(packed), guard);
 }
 
-void tiled_gather_run(hipStream_t st, const TiledConfig& c, float* out, void* workspace, bool accumulate) {
+void tiled_gather_run(hipStream_t st, const TiledConfig& c, float* out, void* workspace, bool accumulate, const Guard& guard) {
     const Geometry g = make_geometry(c.H, c.W, c.R, c.G, c.N, c.Cout, c.variant);
     GatherArgs a{};
     a.staged = static_cast<const char*>(workspace);
@@ -714,30 +815,14 @@ void tiled_gather_run(hipStream_t st, const TiledConfig& c, float* out, void* wo
     a.nfb = (c.Cout + g.fb - 1) / g.fb;
     a.plane_bytes = (unsigned)g.plane_bytes;
     a.strip_off = (unsigned)g.strip_off;
-    a.ut_stride = (unsigned)ut_stride_bytes(c.G, g.fb);
+    a.binned = g.nwin1 > 1 ? 1 : 0;
+    a.guard = guard;
+    a.ut_stride = (unsigned)ut_stride_bytes(c.G, g.fb, g.nwin1 > 1);
     a.zpitch = (unsigned)(g.pw + 2);
     a.debug = c.debug;
     const int grid = ((c.NP * c.patches + g.sk - 1) / g.sk) * a.nfb;
     const size_t lds = lds_bytes(c, g);
-    switch (c.variant) {
-        case 0: launch_variant<GatherTraits<7, 7, 72, true, 2>>(st, a, grid, lds); break;
-        case 1: launch_variant<GatherTraits<7, 7, 104, true, 2>>(st, a, grid, lds); break;
-        case 2: launch_variant<GatherTraits<4, 4, 72, true, 1>>(st, a, grid, lds); break;
-        case 3: launch_variant<GatherTraits<2, 2, 40, true, 1>>(st, a, grid, lds); break;
-        case 4: launch_variant<GatherTraits<3, 3, 40, true, 1>>(st, a, grid, lds); break;
-        case 5: launch_variant<GatherTraits<1, 1, 40, true, 1>>(st, a, grid, lds); break;
-        case 6: launch_variant<GatherTraits<4, 4, 40, false, 1>>(st, a, grid, lds); break;
-        case 7: launch_variant<GatherTraits<7, 7, 72, true, 3>>(st, a, grid, lds); break;
-        case 8: launch_variant<GatherTraits<4, 4, 72, true, 2, 2, 26624>>(st, a, grid, lds); break;
-        case 9: launch_variant<GatherTraits<3, 3, 40, true, 2, 4, 13312>>(st, a, grid, lds); break;
-        case 10: launch_variant<GatherTraits<2, 2, 40, true, 1, 4, 10240, 8>>(st, a, grid, lds); break;
-        case 11: launch_variant<GatherTraits<1, 1, 40, true, 1, 4, 7168, 16>>(st, a, grid, lds); break;
-        case 12: launch_variant<GatherTraits<4, 4, 40, false, 2, 3, 13312>>(st, a, grid, lds); break;
-        case 13: launch_variant<GatherTraits<3, 3, 40, false, 1, 2, 10240, 8>>(st, a, grid, lds); break;
-        case 14: launch_variant<GatherTraits<2, 2, 40, false, 1, 4, 8192, 8>>(st, a, grid, lds); break;
-        case 15: launch_variant<GatherTraits<1, 1, 40, false, 1, 8, 5120, 16>>(st, a, grid, lds); break;
-        default: break;
-    }
+    dispatch_variant(c.variant, st, &a, grid, lds);
 }
 
 }  // namespace dau

@@ -25,7 +25,8 @@ __device__ __forceinline__ void unit_math(float m1, float m2, bool interp, int& 
 __global__ void prepare_units_kernel(const float* __restrict__ w, const float* __restrict__ mu1,
                                      const float* __restrict__ mu2, int S, int G, int F, int ignore,
                                      int flags, int bucket, int transposed_negated, int weight_mode,
-                                     UnitRef* __restrict__ table, Status* __restrict__ status) {
+                                     UnitRef* __restrict__ table, Status* __restrict__ status,
+                                     Status* __restrict__ host_status) {
     const long units = (long)S * G * F;
     unsigned int local_max = 0, local_nan = 0;
     // the loop index is the DESTINATION slot, so that the 24-byte table entries are written in order; in the transposed
@@ -68,18 +69,29 @@ __global__ void prepare_units_kernel(const float* __restrict__ w, const float* _
             for (int i = 1; i < nw; ++i) { local_max = max(local_max, smax[i]); local_nan |= snan[i]; }
             atomicMax(&status->max_abs_mu_bits, local_max);
             if (local_nan) atomicOr(&status->nan_seen, 1u);
+            if (host_status) {
+                // the workgroup that finishes last mirrors the result into pinned host memory (read without a sync by
+                // dau_conv_last_status and as the next call's offset-bucket hint); pad[0] counts finished workgroups
+                __threadfence();
+                if (atomicAdd(&status->pad[0], 1u) == gridDim.x - 1) {
+                    const unsigned mx = atomicMax(&status->max_abs_mu_bits, 0u), nn = atomicOr(&status->nan_seen, 0u);
+                    volatile unsigned* h = reinterpret_cast<volatile unsigned*>(host_status);
+                    h[0] = mx; h[1] = nn; h[2] = 1u;   // [2]: a completed call has reported
+                }
+            }
         }
     }
 }
 
 void launch_prepare_units(hipStream_t st, const float* w, const float* mu1, const float* mu2, Shape sh,
                           int ignore, int flags, int bucket, bool transposed_negated, UnitRef* table,
-                          Status* status) {
+                          Status* status, Status* host_status) {
     const long units = (long)sh.S * sh.G * sh.F;
     const int block = 256;
     const int grid = (int)((units + block - 1) / block < 512 ? (units + block - 1) / block : 512);
     hipLaunchKernelGGL(prepare_units_kernel, dim3(grid), dim3(block), 0, st, w, mu1, mu2, sh.S, sh.G, sh.F,
-                       ignore, flags, bucket, transposed_negated ? 1 : 0, w == nullptr ? 1 : 0, table, status);
+                       ignore, flags, bucket, transposed_negated ? 1 : 0, w == nullptr ? 1 : 0, table, status,
+                       status ? host_status : nullptr);
 }
 
 __global__ void unit_table_export_kernel(const float* __restrict__ mu1, const float* __restrict__ mu2,

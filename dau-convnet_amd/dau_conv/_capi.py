@@ -20,6 +20,7 @@ FLAG_UNIT_TESTING = 1 << 1
 FLAG_SINGLE_DIM_KERNEL = 1 << 2
 FLAG_FORBID_POSITIVE_DIM1 = 1 << 3
 FLAG_IO_BF16 = 1 << 4   # x, y, dy, dx are torch.bfloat16; parameters and their gradients stay float32
+FLAG_STATIC_BUCKET = 1 << 5   # always the kernels of the bucket max_kernel_size allows (no per-call selection)
 
 ALGO_AUTO, ALGO_DIRECT, ALGO_TILED = 0, 1, 2
 PASS_FORWARD, PASS_BACKWARD = 1, 2
@@ -56,7 +57,7 @@ class _Desc(ctypes.Structure):
 class _Info(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ("offset_bucket", "blur_support", "algo_forward", "algo_backward", "drop_last_col", "drop_last_row",
-                 "gather_patch", "gather_stack", "dot_windows")]
+                 "gather_patch", "gather_stack", "dot_windows", "gather_windows", "bucket_sets")]
 
 
 def _load():
@@ -74,12 +75,15 @@ def _load():
     lib.dau_conv_workspace_bytes.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t)]
     lib.dau_conv_forward.argtypes = [vp, vp, fp, fp, fp, fp, fp, fp, vp, ctypes.c_size_t]
     lib.dau_conv_backward.argtypes = [vp, vp] + [fp] * 11 + [vp, ctypes.c_size_t, ctypes.c_int]
+    lib.dau_conv_backward_param_sums.argtypes = [vp, vp] + [fp] * 6 + [vp, ctypes.c_size_t]
+    lib.dau_conv_finalize_param_grads.argtypes = [vp, vp] + [fp] * 6 + [ctypes.c_int]
     lib.dau_conv_check_status.argtypes = [vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
+    lib.dau_conv_last_status.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)]
     lib.dau_conv_filters.argtypes = [vp, vp, fp, fp]
     lib.dau_conv_unit_table.argtypes = [vp, vp, fp, fp, ip, fp]
     lib.dau_conv_profile_begin.argtypes = [vp]
     lib.dau_conv_profile_end.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]
-    if lib.dau_conv_abi_version() != 1:
+    if lib.dau_conv_abi_version() != 2:
         raise ImportError("dau_conv: ABI version mismatch in %s" % _LIB_PATH)
     return lib
 
@@ -99,8 +103,18 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device):
+    """The stream the library launches on: torch's current stream of the tensors' device (not of the current device)."""
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _same_device(*tensors):
+    """All tensors of a call live on one GPU; returns it."""
+    dev = tensors[0].device
+    for t in tensors[1:]:
+        if t is not None and t.device != dev:
+            raise InvalidArgumentError("all tensors of a call must be on the same device (%s vs %s)" % (dev, t.device))
+    return dev
 
 
 def _req(t, name, shape=None, dtype=torch.float32):
@@ -121,11 +135,17 @@ class Plan(object):
     """Owns one dau_conv_plan; scratch memory comes from the per-stream shared workspace."""
 
     def __init__(self, N, S, F, G, H, W, max_kernel_size=9, number_units_ignore=0, flags=FLAG_USE_INTERPOLATION,
-                 algo=ALGO_AUTO, sigma_hint=0.5, mu_learning_rate_factor=1.0):
+                 algo=ALGO_AUTO, sigma_hint=0.5, mu_learning_rate_factor=1.0, device=None):
         d = _Desc(ctypes.sizeof(_Desc), N, S, F, G, H, W, int(max_kernel_size), int(number_units_ignore), int(flags),
                   int(algo), float(sigma_hint), float(mu_learning_rate_factor))
         self._h = ctypes.c_void_p()
-        _check(lib.dau_conv_plan_create(ctypes.byref(d), ctypes.byref(self._h)))
+        # a plan belongs to the device that is current when it is created (its kernels' launch attributes and its pinned
+        # status mirror are set up there); `device` makes that explicit for callers whose current device is another one
+        if device is not None and torch.cuda.is_available():
+            with torch.cuda.device(device):
+                _check(lib.dau_conv_plan_create(ctypes.byref(d), ctypes.byref(self._h)))
+        else:
+            _check(lib.dau_conv_plan_create(ctypes.byref(d), ctypes.byref(self._h)))
         self.N, self.S, self.F, self.G, self.H, self.W = N, S, F, G, H, W
         self.io_dtype = torch.bfloat16 if int(flags) & FLAG_IO_BF16 else torch.float32
         info = _Info()
@@ -159,10 +179,13 @@ class Plan(object):
         _req(x, "input", (self.N, self.S, self.H, self.W), self.io_dtype)
         for t, n in ((w, "weights"), (mu1, "mu1"), (mu2, "mu2"), (sigma, "sigma")):
             _req(t, n, pshape)
-        y = torch.empty((self.N, self.F, self.H, self.W), dtype=self.io_dtype, device=x.device)
-        ws = self._workspace(PASS_FORWARD, x.device)
-        _check(lib.dau_conv_forward(self._h, _stream(), _ptr(x), _ptr(w), _ptr(mu1), _ptr(mu2), _ptr(sigma), _ptr(y),
-                                    _ptr(ws), ws.numel()))
+        dev = _same_device(x, w, mu1, mu2, sigma)
+        # the library launches on the CURRENT device: make that the tensors' device for the duration of the call
+        with torch.cuda.device(dev):
+            y = torch.empty((self.N, self.F, self.H, self.W), dtype=self.io_dtype, device=dev)
+            ws = self._workspace(PASS_FORWARD, dev)
+            _check(lib.dau_conv_forward(self._h, _stream(dev), _ptr(x), _ptr(w), _ptr(mu1), _ptr(mu2), _ptr(sigma), _ptr(y),
+                                        _ptr(ws), ws.numel()))
         self._last_ws = ws
         return y
 
@@ -172,31 +195,77 @@ class Plan(object):
         _req(dy, "grad", (self.N, self.F, self.H, self.W), self.io_dtype)
         for t, n in ((w, "weights"), (mu1, "mu1"), (mu2, "mu2"), (sigma, "sigma")):
             _req(t, n, pshape)
-        dev = x.device
+        dev = _same_device(x, dy, w, mu1, mu2, sigma)
         new = lambda shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        dx = torch.empty(x.shape, dtype=self.io_dtype, device=dev) if need_mask & NEED_DX else None
-        dw = new(pshape) if need_mask & NEED_DW else None
-        dmu1 = new(pshape) if need_mask & NEED_DMU1 else None
-        dmu2 = new(pshape) if need_mask & NEED_DMU2 else None
-        dsigma = new(pshape) if need_mask & NEED_DSIGMA else None
-        ws = self._workspace(PASS_BACKWARD, dev)
-        _check(lib.dau_conv_backward(self._h, _stream(), _ptr(x), _ptr(dy), _ptr(w), _ptr(mu1), _ptr(mu2), _ptr(sigma),
-                                     _ptr(dx), _ptr(dw), _ptr(dmu1), _ptr(dmu2), _ptr(dsigma), _ptr(ws), ws.numel(),
-                                     int(need_mask)))
+        with torch.cuda.device(dev):
+            dx = torch.empty(x.shape, dtype=self.io_dtype, device=dev) if need_mask & NEED_DX else None
+            dw = new(pshape) if need_mask & NEED_DW else None
+            dmu1 = new(pshape) if need_mask & NEED_DMU1 else None
+            dmu2 = new(pshape) if need_mask & NEED_DMU2 else None
+            dsigma = new(pshape) if need_mask & NEED_DSIGMA else None
+            ws = self._workspace(PASS_BACKWARD, dev)
+            _check(lib.dau_conv_backward(self._h, _stream(dev), _ptr(x), _ptr(dy), _ptr(w), _ptr(mu1), _ptr(mu2), _ptr(sigma),
+                                         _ptr(dx), _ptr(dw), _ptr(dmu1), _ptr(dmu2), _ptr(dsigma), _ptr(ws), ws.numel(),
+                                         int(need_mask)))
         self._last_ws = ws
         return dx, dw, dmu1, dmu2, dsigma
+
+    def backward_param_sums(self, x, dy, mu1, mu2, sigma, out=None):
+        """Raw parameter-gradient sums [4, S, G, F] (kinds w, mu1, mu2, sigma) of this batch: linear in the batch, so a
+        data-parallel caller all-reduces THIS buffer and only then calls finalize_param_grads()."""
+        pshape = (1, self.S, self.G, self.F)
+        _req(x, "input", (self.N, self.S, self.H, self.W), self.io_dtype)
+        _req(dy, "grad", (self.N, self.F, self.H, self.W), self.io_dtype)
+        for t, n in ((mu1, "mu1"), (mu2, "mu2"), (sigma, "sigma")):
+            _req(t, n, pshape)
+        dev = _same_device(x, dy, mu1, mu2, sigma, out)
+        with torch.cuda.device(dev):
+            if out is None:
+                out = torch.empty((4, self.S, self.G, self.F), dtype=torch.float32, device=dev)
+            _req(out, "sums", (4, self.S, self.G, self.F))
+            ws = self._workspace(PASS_BACKWARD, dev)
+            _check(lib.dau_conv_backward_param_sums(self._h, _stream(dev), _ptr(x), _ptr(dy), _ptr(mu1), _ptr(mu2), _ptr(sigma),
+                                                    _ptr(out), _ptr(ws), ws.numel()))
+        self._last_ws = ws
+        return out
+
+    def finalize_param_grads(self, sums, w, need_mask=NEED_DW | NEED_DMU1 | NEED_DMU2 | NEED_DSIGMA):
+        """(dw, dmu1, dmu2, dsigma) from (all-reduced) sums: dmu *= w * lr, dsigma *= w, ignored units -> 0, NaN dmu -> 0."""
+        pshape = (1, self.S, self.G, self.F)
+        _req(sums, "sums", (4, self.S, self.G, self.F))
+        _req(w, "weights", pshape)
+        dev = _same_device(sums, w)
+        new = lambda: torch.empty(pshape, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            dw = new() if need_mask & NEED_DW else None
+            dmu1 = new() if need_mask & NEED_DMU1 else None
+            dmu2 = new() if need_mask & NEED_DMU2 else None
+            dsigma = new() if need_mask & NEED_DSIGMA else None
+            _check(lib.dau_conv_finalize_param_grads(self._h, _stream(dev), _ptr(sums), _ptr(w), _ptr(dw), _ptr(dmu1),
+                                                     _ptr(dmu2), _ptr(dsigma), int(need_mask)))
+        return dw, dmu1, dmu2, dsigma
 
     def check_status(self):
         """Sync + raise if the last call saw NaN or out-of-bucket offsets; returns max(|mu|)."""
         mx = ctypes.c_float()
-        _check(lib.dau_conv_check_status(self._h, _stream(), _ptr(self._last_ws), ctypes.byref(mx)))
+        dev = self._last_ws.device
+        with torch.cuda.device(dev):
+            _check(lib.dau_conv_check_status(self._h, _stream(dev), _ptr(self._last_ws), ctypes.byref(mx)))
         return mx.value
+
+    def last_status(self):
+        """No sync: max(|mu|) seen by the most recent COMPLETED call of this plan (None before any has completed);
+        raises if that call saw NaN or out-of-bucket offsets.  Calling it before every op call surfaces a bad offset
+        one call late without ever stalling the stream."""
+        mx, valid = ctypes.c_float(), ctypes.c_int32()
+        _check(lib.dau_conv_last_status(self._h, ctypes.byref(mx), ctypes.byref(valid)))
+        return mx.value if valid.value else None
 
     def profile_begin(self):
         _check(lib.dau_conv_profile_begin(self._h))
 
     def profile_end(self):
-        """-> {slot name: (summed ms, launches)} for the dominant kernels since profile_begin()."""
+        """-> {slot name: (summed ms of the dominant kernel's launches, passes they made up)} since profile_begin()."""
         ms = (ctypes.c_double * 3)()
         n = (ctypes.c_int32 * 3)()
         _check(lib.dau_conv_profile_end(self._h, ms, n))
@@ -205,12 +274,14 @@ class Plan(object):
     def filters(self, sigma):
         k = self.info["blur_support"]
         out = torch.empty((6, k, k), dtype=torch.float32, device=sigma.device)
-        _check(lib.dau_conv_filters(self._h, _stream(), _ptr(sigma), _ptr(out)))
+        with torch.cuda.device(sigma.device):
+            _check(lib.dau_conv_filters(self._h, _stream(sigma.device), _ptr(sigma), _ptr(out)))
         return out
 
     def unit_table(self, mu1, mu2):
         units = self.S * self.G * self.F
         off = torch.empty((units, 2), dtype=torch.int32, device=mu1.device)
         fac = torch.empty((units, 4), dtype=torch.float32, device=mu1.device)
-        _check(lib.dau_conv_unit_table(self._h, _stream(), _ptr(mu1), _ptr(mu2), _ptr(off), _ptr(fac)))
+        with torch.cuda.device(mu1.device):
+            _check(lib.dau_conv_unit_table(self._h, _stream(mu1.device), _ptr(mu1), _ptr(mu2), _ptr(off), _ptr(fac)))
         return off, fac

@@ -28,7 +28,7 @@ import torch.nn as nn
 from . import _capi
 
 __all__ = ["DAUGridMean", "ZeroNLast", "DAUConv2d", "DAUConv1d", "dau_conv2d", "dau_conv1d", "dau_conv",
-           "dau_conv_grad"]
+           "dau_conv_grad", "check_pending_offsets"]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -65,16 +65,40 @@ def _get_plan(x, w, settings):
     if plan is None:
         plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=settings["kernel_size"],
                           number_units_ignore=settings["number_units_ignore"], flags=flags, algo=settings["algo"],
-                          sigma_hint=settings["sigma_hint"], mu_learning_rate_factor=settings["mu_learning_rate_factor"])
+                          sigma_hint=settings["sigma_hint"], mu_learning_rate_factor=settings["mu_learning_rate_factor"],
+                          device=x.device)
         _PLANS[key] = plan
     return plan
+
+
+def _check_before(plan, mode):
+    """check_offsets="async": before enqueueing a call, look at what the plan's most recent COMPLETED call reported
+    (pinned host memory, no sync) and raise the reference's errors for it (NaN -> FailedPrecondition, offsets beyond the
+    kernel -> InvalidArgument, dau_conv_op.cpp:250-262) -- one call late, without stalling the stream."""
+    if mode == "async":
+        plan.last_status()
+
+
+def _check_after(plan, mode):
+    """check_offsets=True: the reference's behaviour -- wait for the call and raise at once (the reference blocks on a
+    D2H copy of the amax in every Compute, dau_conv_op.cpp:229-235)."""
+    if mode is True:
+        plan.check_status()
+
+
+def check_pending_offsets(device=None):
+    """Wait for the device and raise if any plan's latest call saw a NaN / out-of-range offset (for check_offsets="async"
+    users: call at the end of a step or before reading results)."""
+    torch.cuda.synchronize(device)
+    for plan in list(_PLANS.values()):
+        plan.last_status()
 
 
 def _settings(sigma, number_units_x=2, number_units_y=2, number_units_ignore=0, num_output=64, kernel_size=9, pad=4,
               stride=1, unit_normalization=True, square_unit_normalization=False, mean_iteration_step=1,
               sigma_iteration_step=1, component_border_bound=1.0, sigma_lower_bound=0.3, merge_iteration_step=0,
               merge_threshold=1, unit_testing=False, mu_learning_rate_factor=1.0, single_dim_kernel=False,
-              forbid_positive_dim1=False, use_interpolation=True, sigma_hint=None, check_offsets=True,
+              forbid_positive_dim1=False, use_interpolation=True, sigma_hint=None, check_offsets="async",
               algo=_capi.ALGO_AUTO, name=None):
     if not unit_normalization or square_unit_normalization:
         raise _capi.InvalidArgumentError("only unit_normalization=True, square_unit_normalization=False is implemented")
@@ -84,7 +108,8 @@ def _settings(sigma, number_units_x=2, number_units_y=2, number_units_ignore=0, 
     return dict(number_units_ignore=int(number_units_ignore), num_output=int(num_output), kernel_size=int(kernel_size),
                 stride=int(stride), unit_testing=bool(unit_testing), mu_learning_rate_factor=float(mu_learning_rate_factor),
                 single_dim_kernel=bool(single_dim_kernel), forbid_positive_dim1=bool(forbid_positive_dim1),
-                use_interpolation=bool(use_interpolation), sigma_hint=float(sigma_hint), check_offsets=bool(check_offsets),
+                use_interpolation=bool(use_interpolation), sigma_hint=float(sigma_hint),
+                check_offsets=(check_offsets if check_offsets in (True, False, "async") else bool(check_offsets)),
                 algo=int(algo))
 
 
@@ -97,9 +122,9 @@ def dau_conv_grad(grad, input, weights, mu1, mu2, sigma, need_mask=_capi.NEED_AL
     attrs.setdefault("component_border_bound", 0.0)  # the only default that differs (dau_conv_grad_op.cpp:37)
     st = _settings(sigma, **attrs)
     plan = _get_plan(input, weights, st)
+    _check_before(plan, st["check_offsets"])
     out = plan.backward(_c(input), _c(grad), _c(weights), _c(mu1), _c(mu2), _c(sigma), need_mask)
-    if st["check_offsets"]:
-        plan.check_status()
+    _check_after(plan, st["check_offsets"])
     return out
 
 
@@ -108,9 +133,9 @@ class _DAUConvFunction(torch.autograd.Function):
     def forward(ctx, input, weights, mu1, mu2, sigma, st):
         input, weights, mu1, mu2, sigma = _c(input), _c(weights), _c(mu1), _c(mu2), _c(sigma)
         plan = _get_plan(input, weights, st)
+        _check_before(plan, st["check_offsets"])
         y = plan.forward(input, weights, mu1, mu2, sigma)
-        if st["check_offsets"]:
-            plan.check_status()
+        _check_after(plan, st["check_offsets"])
         ctx.save_for_backward(input, weights, mu1, mu2, sigma)
         ctx.plan, ctx.st = plan, st
         return y
@@ -124,9 +149,9 @@ class _DAUConvFunction(torch.autograd.Function):
                 need |= bit
         if need == 0:
             return (None,) * 6
+        _check_before(ctx.plan, ctx.st["check_offsets"])
         out = ctx.plan.backward(input, _c(grad), weights, mu1, mu2, sigma, need)
-        if ctx.st["check_offsets"]:
-            ctx.plan.check_status()
+        _check_after(ctx.plan, ctx.st["check_offsets"])
         return out + (None,)
 
 
@@ -237,7 +262,7 @@ class _DAUConvolution2d(object):
     def __init__(self, input_shape, num_output, dau_units, max_kernel_size, padding, data_format=None, strides=None,
                  num_dau_units_ignore=0, mu_learning_rate_factor=500, dau_unit_border_bound=0.01,
                  dau_unit_sigma_bound=0.01, dau_unit_single_dim=False, dau_aggregation_forbid_positive_dim1=False,
-                 dau_mu_interpolation=True, unit_testing=False, name=None, check_offsets=True, algo=_capi.ALGO_AUTO):
+                 dau_mu_interpolation=True, unit_testing=False, name=None, check_offsets="async", algo=_capi.ALGO_AUTO):
         if len(input_shape) != 4:
             raise ValueError("Only two dimensional DAUConv supported (rank-4 NCHW input).")
         if data_format is None or data_format == "NHWC":
@@ -282,7 +307,14 @@ class _DAUConvolution2d(object):
 
 
 class DAUConv2d(nn.Module):
-    """DAU convolution layer; constructor arguments as in the reference (dau_conv.py:226-258)."""
+    """DAU convolution layer; constructor arguments as in the reference (dau_conv.py:226-258).
+
+    Additions: `in_channels` (build the variables at construction), `algo`, and `check_offsets`: how the op's offset
+    preconditions (NaN, |mu| beyond the kernel; dau_conv_op.cpp:250-262) are enforced -- "async" (default): read the
+    previous call's on-device result from pinned host memory before each call, no stall, errors surface one call late
+    (`dau_conv.check_pending_offsets()` flushes); True: wait for every call and raise at once, as the reference does;
+    False: never read the result back.
+    """
 
     # the reference kernels process units in pairs; odd unit counts get one zero-weight ignored unit
     DAU_UNITS_GROUP = 2
@@ -294,7 +326,7 @@ class DAUConv2d(nn.Module):
                  weight_constraint=None, mu1_constraint=None, mu2_constraint=None, sigma_constraint=None,
                  bias_constraint=None, trainable=True, mu_learning_rate_factor=500, dau_unit_border_bound=0.01,
                  dau_unit_single_dim=False, dau_aggregation_forbid_positive_dim1=False, dau_sigma_trainable=False,
-                 dau_mu_interpolation=True, unit_testing=False, name=None, in_channels=None, check_offsets=True,
+                 dau_mu_interpolation=True, unit_testing=False, name=None, in_channels=None, check_offsets="async",
                  algo=_capi.ALGO_AUTO, **kwargs):
         super(DAUConv2d, self).__init__()
         self.rank = 2
@@ -357,6 +389,7 @@ class DAUConv2d(nn.Module):
         self.dau_sigma_trainable = dau_sigma_trainable
         self._manual = {}
         self._sigma_host = None
+        self._sigma_tag = None
         self.built = False
         if self.strides > 1:
             warnings.warn('NOTICE: using stride>=2 in DAU convolution uses the same computational resources as with '
@@ -445,8 +478,13 @@ class DAUConv2d(nn.Module):
         s = self.dau_sigma
         if s.numel() == 1:
             # tile the scalar to the parameter shape, as the reference graph does (dau_conv.py:429-430)
-            if self._sigma_host is None or self.dau_sigma_trainable:
+            # the host copy sizes the prefilter support (2*ceil(5*sigma)+1, base_dau_conv_layer.cpp:146) and keys the plan; it
+            # is re-read whenever the tensor has been written since (optimizer step, load_state_dict, constraints,
+            # set_dau_variables_manually): the reference re-reads sigma every time it builds its layer (:140-146)
+            tag = (s._version, s.data_ptr())
+            if self._sigma_host is None or self._sigma_tag != tag:
                 self._sigma_host = float(s.detach().reshape(-1)[0].item())
+                self._sigma_tag = tag
             return s.reshape(1, 1, 1, 1).expand(self._param_shape), self._sigma_host
         return s, None
 

@@ -22,9 +22,15 @@
  *   dau_conv_backward                 DAUConvGradOp::Compute (plugins/tensorflow/src/dau_conv_grad_op.cpp:115-318)
  *                                     -> BaseDAUConvLayer::Backward_gpu (base_dau_conv_layer.cu:130-363)
  *                                     -> DAUConvBackward::backward_pass (dau_conv_backward.cpp:173-232)
- *   dau_conv_check_status             the max|mu| / NaN precondition checks of the ops
- *                                     (dau_conv_op.cpp:223-262, dau_conv_grad_op.cpp:209-250); done on the
- *                                     device without a host sync, read back only on request
+ *   dau_conv_backward_param_sums /    the two halves of Backward_gpu's parameter-gradient path: the raw sums of K4
+ *   dau_conv_finalize_param_grads     (base_dau_conv_layer.cu:232-241) and its elementwise tail (dmu *= w, ignored units,
+ *                                     NaN -> 0, :335-355; lr factor, dau_conv_grad_op.cpp:297-303), split so that a
+ *                                     data-parallel caller can all-reduce the sums in between
+ *   dau_conv_check_status /           the max|mu| / NaN precondition checks of the ops
+ *   dau_conv_last_status              (dau_conv_op.cpp:223-262, dau_conv_grad_op.cpp:209-250); done on the
+ *                                     device without a host sync, read back only on request (check_status waits for
+ *                                     the stream; last_status reads what the most recent completed call left in
+ *                                     pinned host memory, without waiting)
  *   dau_conv_filters                  BaseDAUKernelCompute::get_kernels (base_dau_conv_layer.cu:537-710)
  *   dau_conv_unit_table               perpare_weights_and_offsets (dau_conv_forward_core.hpp:1858-2215)
  *   dau_conv_last_error               DAUException::what (include/dau_conv/util/common.hpp:40-66)
@@ -35,11 +41,20 @@
  * full [1,S,G,F] tensor whose element 0 is used (base_dau_conv_layer.hpp:266-275).
  *
  * Ownership: the caller owns every buffer, including one workspace per in-flight call.
- * A plan is immutable after creation, so concurrent calls on different streams with
- * different workspaces are safe.  No call allocates, frees or synchronises, except
- * dau_conv_check_status (which waits for the stream).  dau_conv_backward OVERWRITES
- * the gradient outputs (the reference op zero-fills them and then accumulates,
- * dau_conv_grad_op.cpp:202-205 -- same net result).
+ * A plan's configuration is immutable after creation, so concurrent calls on different
+ * streams with different workspaces are safe.  Only dau_conv_plan_create / _destroy allocate
+ * (the plan and 16 bytes of pinned host memory for its status mirror) and only
+ * dau_conv_check_status synchronises (it waits for the stream); no other call allocates,
+ * frees or synchronises.  Create a plan with the device current on which it will run.
+ * dau_conv_backward OVERWRITES the gradient outputs (the reference op zero-fills them and
+ * then accumulates, dau_conv_grad_op.cpp:202-205 -- same net result).
+ *
+ * Offset buckets.  The kernels stage a border of R pixels around every tile, R in
+ * {4, 8, 16, 24, 32}.  The reference picks R per call from a blocking amax of mu1/mu2
+ * (dau_conv_op.cpp:223-253).  Here a plan holds the kernel sets of every R up to the one
+ * max_kernel_size allows; a call enqueues the set that covered the previous call's max|mu|
+ * (read from the pinned mirror, no sync) plus the largest set, each guarded on the device by
+ * THIS call's max|mu|, so exactly one does the work and results never depend on the hint.
  */
 #ifndef DAU_CONV_H_
 #define DAU_CONV_H_
@@ -51,7 +66,7 @@
 extern "C" {
 #endif
 
-#define DAU_CONV_ABI_VERSION 1
+#define DAU_CONV_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define DAU_API __attribute__((visibility("default")))
@@ -78,6 +93,8 @@ enum {
                                                float* parameters); parameters, their gradients and all
                                                arithmetic stay fp32.  Needs the tiled kernels: plan
                                                creation fails where only the direct ones apply.        */
+    DAU_FLAG_STATIC_BUCKET = 1 << 5,        /* always run the kernels of the bucket max_kernel_size allows (no
+                                               per-call selection from the actual offsets)             */
     DAU_FLAG_DEFAULT = DAU_FLAG_USE_INTERPOLATION
 };
 
@@ -108,7 +125,8 @@ typedef struct dau_conv_desc {
     int32_t out_channels;           /* F  (attr num_output)                                       */
     int32_t units_per_channel;      /* G  (number_units_x * number_units_y, incl. ignored units)  */
     int32_t height, width;          /* H, W (output size == input size, dau_conv_op.cpp:185-188)  */
-    int32_t max_kernel_size;        /* attr kernel_size: 9/17/33/65 -> offset bucket 4/8/16/32    */
+    int32_t max_kernel_size;        /* attr kernel_size: 9/17/33/49/65 -> largest offset bucket
+                                       4/8/16/24/32                                               */
     int32_t number_units_ignore;    /* attr number_units_ignore                                   */
     int32_t flags;                  /* DAU_FLAG_*                                                 */
     int32_t algo;                   /* DAU_ALGO_*                                                 */
@@ -121,7 +139,7 @@ typedef struct dau_conv_desc {
 typedef struct dau_conv_plan dau_conv_plan; /* opaque */
 
 typedef struct dau_conv_plan_info {
-    int32_t offset_bucket;     /* R in {4,8,16,32}                                                */
+    int32_t offset_bucket;     /* largest (static) R in {4,8,16,24,32}                            */
     int32_t blur_support;      /* k of the k x k prefilter                                        */
     int32_t algo_forward;      /* DAU_ALGO_* actually used by dau_conv_forward / the dx pass      */
     int32_t algo_backward;     /* DAU_ALGO_* actually used for the parameter gradients            */
@@ -129,7 +147,9 @@ typedef struct dau_conv_plan_info {
     int32_t drop_last_row;     /* ... and H                                                       */
     int32_t gather_patch;      /* tiled gather-sum: pixels per patch side (0: direct kernel)      */
     int32_t gather_stack;      /* ... and (image pair, patch) planes gathered per workgroup       */
-    int32_t dot_windows;       /* tiled gather-dot: offset-window passes (1 for kernels <= 17)    */
+    int32_t dot_windows;       /* tiled gather-dot: offset windows (1 for kernels <= 17)          */
+    int32_t gather_windows;    /* tiled gather-sum: offset-window passes (1 for kernels <= 33)    */
+    int32_t bucket_sets;       /* kernel sets a call can choose from (1: static bucket only)      */
 } dau_conv_plan_info;
 
 DAU_API int dau_conv_abi_version(void);
@@ -150,11 +170,28 @@ DAU_API int dau_conv_backward(const dau_conv_plan *plan, void *stream, const flo
                       float *dx, float *dw, float *dmu1, float *dmu2, float *dsigma,
                       void *workspace, size_t workspace_bytes, int need_mask);
 
+/* The parameter-gradient path of dau_conv_backward in two steps, for data-parallel callers (batch sharded over
+ * ranks): _param_sums writes the raw sums r[k][s][g][f], k = {w, mu1, mu2, sigma} (4*S*G*F floats, linear in the
+ * batch) into sums_out; the caller all-reduces that ONE flat buffer; _finalize_param_grads then applies the
+ * elementwise tail on the reduced sums (dw = r0, dmu1 = w*r1*lr, dmu2 = w*r2*lr, dsigma = w*r3, ignored units -> 0,
+ * NaN in dmu -> 0), so that every rank ends up bit-identical and a NaN on one rank is not zeroed before the exchange.
+ * dau_conv_backward(need_mask of the four) == _param_sums followed by _finalize_param_grads. */
+DAU_API int dau_conv_backward_param_sums(const dau_conv_plan *plan, void *stream, const float *x, const float *dy,
+                                 const float *mu1, const float *mu2, const float *sigma, float *sums_out,
+                                 void *workspace, size_t workspace_bytes);
+DAU_API int dau_conv_finalize_param_grads(const dau_conv_plan *plan, void *stream, const float *sums, const float *w,
+                                  float *dw, float *dmu1, float *dmu2, float *dsigma, int need_mask);
+
 /* Waits for `stream`, then reports what the last call that used `workspace` found in mu1/mu2:
  * DAU_OK, DAU_FAILED_PRECONDITION (NaN) or DAU_INVALID_ARGUMENT (|mu| beyond the bucket).
  * max_abs_mu_out (may be NULL) receives max(|mu1|,|mu2|). */
 DAU_API int dau_conv_check_status(const dau_conv_plan *plan, void *stream, const void *workspace,
                           float *max_abs_mu_out);
+
+/* The same report without waiting: what the most recent COMPLETED forward/backward call of this plan found (read
+ * from pinned host memory).  valid_out = 0 when no call has completed yet (then DAU_OK).  A caller that checks this
+ * before each call learns of a NaN / out-of-range offset one call late, without ever stalling the stream. */
+DAU_API int dau_conv_last_status(const dau_conv_plan *plan, float *max_abs_mu_out, int32_t *valid_out);
 
 /* Building blocks exposed for parity tests (device pointers in and out).
  * filters_out: 6 planes of k*k floats in the order Gn, Dw, Dmu1, Dmu2, Dsigma, Gerr.
@@ -167,11 +204,12 @@ DAU_API int dau_conv_unit_table(const dau_conv_plan *plan, void *stream, const f
  * compile-time PROFILE_CUDA block, dau_conv_forward_core.hpp:2506-2563).  Between _begin and _end every
  * dominant kernel launch is bracketed by HIP events on the caller's stream (asynchronous, no host sync).
  * Slots: 0 = gather-sum of dau_conv_forward, 1 = gather-sum of the dx pass, 2 = gather-dot (parameter
- * gradients).  _end waits for the events and returns summed milliseconds and launch counts per slot.
+ * gradients).  _end waits for the events and returns, per slot, the summed milliseconds of those launches and the
+ * number of PASSES they made up (a pass over large offsets takes several window launches).
  * Not thread-safe; one profiling session per plan at a time. */
 enum { DAU_PROFILE_SLOTS = 3 };
 DAU_API int dau_conv_profile_begin(dau_conv_plan *plan);
-DAU_API int dau_conv_profile_end(dau_conv_plan *plan, double *ms_out, int32_t *launches_out);
+DAU_API int dau_conv_profile_end(dau_conv_plan *plan, double *ms_out, int32_t *passes_out);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 """CPU, world_size 2, gloo: the batch-sharded data-parallel path.  Each rank computes the parameter
-gradients of its batch shard (here with the CPU oracle, since there is no GPU in this suite), the flat
-[dw|dmu1|dmu2|dsigma] bucket is all-reduced, and the result must equal the full-batch gradients."""
+gradient SUMS of its batch shard (here with the CPU oracle's building blocks, since there is no GPU in this suite), the
+flat [4,S,G,F] buffer of raw sums is all-reduced, the elementwise tail (dmu *= w*lr, ...) runs AFTER the exchange
+(SURVEY.md 8e), and the result must equal the full-batch gradients."""
 import os
 import sys
 
@@ -30,25 +31,43 @@ def _worker(rank, world, port, out_dir):
     mu1 = rs.uniform(-3, 3, (1, S, G, F)).astype(np.float32)
     mu2 = rs.uniform(-3, 3, (1, S, G, F)).astype(np.float32)
     lo, hi = ddp.shard_bounds(N, rank, world)
-    g = orc.backward(x[lo:hi], dy[lo:hi], w, mu1, mu2, 0.5, need=("dw", "dmu1", "dmu2", "dsigma"))
-    red = ddp.all_reduce_param_grads(*(torch.from_numpy(g[k]) for k in ("dw", "dmu1", "dmu2", "dsigma")))
-    # the same exchange through the overlapped form bench.py uses for N>1 (need-mask split, async all-reduce)
-    from dau_conv import _capi as cc
-    names = {cc.NEED_DX: "dx", cc.NEED_DW: "dw", cc.NEED_DMU1: "dmu1", cc.NEED_DMU2: "dmu2", cc.NEED_DSIGMA: "dsigma"}
+    lr = 3.0
+    filt = orc.filters(0.5)
 
-    def backward_fn(need_mask):
-        need = tuple(v for k, v in names.items() if need_mask & k)
-        o = orc.backward(x[lo:hi], dy[lo:hi], w, mu1, mu2, 0.5, need=need)
-        return tuple(torch.from_numpy(o[k]) if o.get(k) is not None else None for k in ("dx", "dw", "dmu1", "dmu2", "dsigma"))
+    # the three callables of OverlappedBackward, here from the oracle's building blocks (on the GPU they are
+    # Plan.backward_param_sums / Plan.backward(NEED_DX) / Plan.finalize_param_grads)
+    def sums_fn(out):
+        for k, name in enumerate(("Dw", "Dmu1", "Dmu2", "Dsigma")):
+            out[k] = torch.from_numpy(orc.offset_and_dot(orc.blur(x[lo:hi], filt[name]), dy[lo:hi], mu1, mu2)[0])
+
+    def dx_fn():
+        return torch.from_numpy(orc.backward(x[lo:hi], dy[lo:hi], w, mu1, mu2, 0.5, need=("dx",))["dx"])
+
+    order = []
+
+    def finalize_fn(sums):
+        order.append("finalize")
+        wt = torch.from_numpy(w)
+        return sums[0:1].clone(), sums[1:2] * wt * lr, sums[2:3] * wt * lr, sums[3:4] * wt
 
     ex = ddp.OverlappedBackward(w.shape, torch.device("cpu"))
-    dx_shard = ex.run(backward_fn)
-    red2 = ex.wait()
+    local = torch.empty_like(ex.sums)
+    sums_fn(local)
+    dx_shard = ex.run(sums_fn, dx_fn, finalize_fn)
+    assert order == [], "finalize must not run before the exchange has been joined"
+    red = ex.wait()
+    assert order == ["finalize"]
     assert dx_shard.shape == (hi - lo, S, H, W)
-    for a, b in zip(red, red2):
-        assert torch.equal(a, b)
+    # the buffer that travelled holds the SUM over ranks of the raw sums (not of finalized gradients)
+    gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    assert torch.allclose(ex.sums, sum(gathered), rtol=1e-6, atol=1e-7)
+    # same result through the plain helper
+    again = local.clone()
+    ddp.all_reduce_param_sums(again)
+    assert torch.equal(again, ex.sums)
     if rank == 0:
-        full = orc.backward(x, dy, w, mu1, mu2, 0.5, need=("dw", "dmu1", "dmu2", "dsigma"))
+        full = orc.backward(x, dy, w, mu1, mu2, 0.5, mu_learning_rate_factor=lr, need=("dw", "dmu1", "dmu2", "dsigma"))
         np.savez(os.path.join(out_dir, "r.npz"), **{k: v.numpy() for k, v in zip(("dw", "dmu1", "dmu2", "dsigma"), red)},
                  **{"full_" + k: full[k] for k in ("dw", "dmu1", "dmu2", "dsigma")})
     dist.barrier()

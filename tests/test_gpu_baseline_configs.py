@@ -1,0 +1,177 @@
+"""GPU parity at the BASELINE.json workloads themselves (HIP path through the C ABI vs the CPU oracle, all six tensors):
+
+  NS   N=32 of the north-star batch: S=F=256, 56x56, G=4, k=9 -- incl. dw / dmu1 / dmu2 / dsigma at full channel counts
+  C1   AlexNet-DAU conv2 at full size: N=64, 96->256, 27x27, G=4
+  C2   56x56 with SIX units and bfloat16 activations, S=F=256, odd batch
+  C4   512x512 maps, 9 live units (10 stored, 1 ignored), max_kernel_size 65, mu ~ U(-17,17): every window / patch path
+       of the real config, at a channel count the oracle finishes in seconds
+  dyn  the reference's "big kernel, small offsets" cases (dau_conv_test.py:433,436: kernel 17 with |mu| <= 3) and the
+       per-call offset-bucket selection: results must not depend on the hint, the small-offset kernels must be the ones
+       that run.
+
+(C3 = C1/NS kernels on 8 ranks; its exchange is covered by test_distributed_cpu.py / test_gpu_distributed.py.)
+Tolerance: 1e-4 relative + 1e-6 of the max-norm (fp32, north star); bf16 outputs 2e-2 / 4e-3.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dau_oracle as orc
+from util import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(seed, N, S, F, G, H, W, k, m, ignore=0):
+    rs = np.random.RandomState(seed)
+    x = rs.rand(N, S, H, W).astype(np.float32)
+    dy = rs.randn(N, F, H, W).astype(np.float32)
+    w = (rs.randn(1, S, G, F) * 0.1).astype(np.float32)
+    if ignore:
+        w[:, :, G - ignore:, :] = 0.0
+    lim = k // 2 - 0.01
+    mu1 = np.clip(rs.uniform(-m, m, (1, S, G, F)), -lim, lim).astype(np.float32)
+    mu2 = np.clip(rs.uniform(-m, m, (1, S, G, F)), -lim, lim).astype(np.float32)
+    return x, dy, w, mu1, mu2
+
+
+def _run(plan, x, dy, w, mu1, mu2, dtype=torch.float32, calls=1):
+    dev = lambda a: torch.from_numpy(a).cuda()
+    S, G, F = w.shape[1:]
+    sigma = torch.full((1, S, G, F), 0.5, device="cuda")
+    xd, dyd = dev(x).to(dtype), dev(dy).to(dtype)
+    wd, m1, m2 = dev(w), dev(mu1), dev(mu2)
+    for _ in range(calls):
+        y = plan.forward(xd, wd, m1, m2, sigma)
+        plan.check_status()
+        g = plan.backward(xd, dyd, wd, m1, m2, sigma)
+        plan.check_status()
+    torch.cuda.synchronize()
+    return dict(y=y.float().cpu().numpy(), dx=g[0].float().cpu().numpy(), dw=g[1].cpu().numpy(), dmu1=g[2].cpu().numpy(),
+                dmu2=g[3].cpu().numpy(), dsigma=g[4].cpu().numpy())
+
+
+def _check_all(got, x, dy, w, mu1, mu2, name, ignore=0, io_rel=1e-4, io_floor=1e-6):
+    want_y = orc.forward(x, w, mu1, mu2, 0.5, ignore=ignore)
+    want = orc.backward(x, dy, w, mu1, mu2, 0.5, ignore=ignore)
+    assert_parity(got["y"], want_y, name + "/y", rel=io_rel, floor=io_floor)
+    assert_parity(got["dx"], want["dx"], name + "/dx", rel=io_rel, floor=io_floor)
+    for key in ("dw", "dmu1", "dmu2", "dsigma"):
+        assert_parity(got[key], want[key], name + "/" + key)
+
+
+def test_ns_channel_counts_all_six_tensors():
+    """North-star layer (S=F=256, 56x56, G=4, k=9) on 32 images: parameter gradients compared with the oracle directly."""
+    from dau_conv import _capi
+    N, S, F, G, H, W, k = 32, 256, 256, 4, 56, 56, 9
+    x, dy, w, mu1, mu2 = _inputs(21, N, S, F, G, H, W, k, 3.0)
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, sigma_hint=0.5)
+    assert plan.info["algo_forward"] == _capi.ALGO_TILED and plan.info["algo_backward"] == _capi.ALGO_TILED
+    _check_all(_run(plan, x, dy, w, mu1, mu2), x, dy, w, mu1, mu2, "NS")
+
+
+def test_c1_alexnet_conv2_full_size():
+    from dau_conv import _capi
+    N, S, F, G, H, W, k = 64, 96, 256, 4, 27, 27, 9
+    x, dy, w, mu1, mu2 = _inputs(22, N, S, F, G, H, W, k, 3.0)
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, sigma_hint=0.5)
+    assert plan.info["algo_forward"] == _capi.ALGO_TILED and plan.info["algo_backward"] == _capi.ALGO_TILED
+    _check_all(_run(plan, x, dy, w, mu1, mu2), x, dy, w, mu1, mu2, "C1")
+
+
+def test_c2_six_units_bf16_activations():
+    """BASELINE config 2's combination: 56x56, G=6 (two gather-dot passes), bfloat16 x / y / dy / dx, S=F=256."""
+    from dau_conv import _capi
+    N, S, F, G, H, W, k = 3, 256, 256, 6, 56, 56, 9
+    x, dy, w, mu1, mu2 = _inputs(23, N, S, F, G, H, W, k, 3.0)
+    xb = torch.from_numpy(x).to(torch.bfloat16).float().numpy()      # what the kernels read
+    dyb = torch.from_numpy(dy).to(torch.bfloat16).float().numpy()
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, sigma_hint=0.5,
+                      flags=_capi.FLAG_USE_INTERPOLATION | _capi.FLAG_IO_BF16)
+    got = _run(plan, xb, dyb, w, mu1, mu2, dtype=torch.bfloat16)
+    # bf16 outputs: one rounding to 8 bits (2^-9 relative); the fp32 parameter gradients keep the fp32 bar
+    _check_all(got, xb, dyb, w, mu1, mu2, "C2", io_rel=2e-2, io_floor=4e-3)
+
+
+@pytest.mark.parametrize("static_bucket", [False, True])
+def test_c4_seg_scale_large_offsets(static_bucket):
+    """BASELINE config 4's workload: 512x512, nine live units of ten, kernel 65, offsets within +-17.  With per-call
+    selection the second call runs the bucket-24 kernels (9 gather-dot windows, 4 gather windows of radius 12); with
+    DAU_FLAG_STATIC_BUCKET the bucket-32 ones (16 and 4 windows of radius 16).  Both must match the oracle."""
+    from dau_conv import _capi
+    N, S, F, G, H, W, k = 2, 4, 32, 10, 512, 512, 65
+    x, dy, w, mu1, mu2 = _inputs(24, N, S, F, G, H, W, k, 17.0, ignore=1)
+    flags = _capi.FLAG_USE_INTERPOLATION | (_capi.FLAG_STATIC_BUCKET if static_bucket else 0)
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, number_units_ignore=1, sigma_hint=0.5, flags=flags)
+    assert plan.info["algo_forward"] == _capi.ALGO_TILED and plan.info["algo_backward"] == _capi.ALGO_TILED
+    assert plan.info["offset_bucket"] == 32 and plan.info["bucket_sets"] == (1 if static_bucket else 5)
+    got = _run(plan, x, dy, w, mu1, mu2, calls=2)        # the second call has the first one's max|mu| as its hint
+    _check_all(got, x, dy, w, mu1, mu2, "C4", ignore=1)
+    assert float(np.abs(got["dw"][:, :, G - 1]).max()) == 0.0
+
+
+@pytest.mark.parametrize("shape", [
+    # dau_conv_test.py:433,436,449,455: kernel 17 declared, offsets within +-3
+    dict(N=16, S=32, F=32, G=4, H=32, W=32, k=17, m=3.0),
+    dict(N=16, S=3, F=32, G=4, H=32, W=32, k=17, m=3.0),
+    # the same idea at the largest kernel: 65 declared, offsets within +-3 / +-7 / +-12 / +-20
+    dict(N=4, S=6, F=40, G=4, H=40, W=56, k=65, m=3.0),
+    dict(N=3, S=5, F=24, G=3, H=33, W=47, k=65, m=7.0),
+    dict(N=2, S=4, F=32, G=6, H=64, W=64, k=65, m=12.0),
+    dict(N=2, S=4, F=32, G=5, H=64, W=64, k=65, m=20.0),
+    dict(N=2, S=3, F=16, G=2, H=30, W=70, k=49, m=23.5),
+])
+def test_big_kernel_small_offsets_dynamic_bucket(shape):
+    """Three calls of one plan: without a hint (static bucket), with the hint of the same offsets (small bucket), and
+    after the offsets GREW beyond the hinted bucket (the guard must send the call to the static set).  Every result
+    equals the oracle; the first two are bit-identical whenever the hinted bucket equals the static one."""
+    from dau_conv import _capi
+    N, S, F, G, H, W, k, m = (shape[q] for q in ("N", "S", "F", "G", "H", "W", "k", "m"))
+    x, dy, w, mu1, mu2 = _inputs(31, N, S, F, G, H, W, k, m)
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, sigma_hint=0.5)
+    assert plan.info["bucket_sets"] > 1
+    first = _run(plan, x, dy, w, mu1, mu2)               # no hint yet: static bucket
+    assert plan.last_status() == pytest.approx(float(max(np.abs(mu1).max(), np.abs(mu2).max())))
+    second = _run(plan, x, dy, w, mu1, mu2)              # hinted: smallest bucket that covers max|mu|
+    _check_all(first, x, dy, w, mu1, mu2, "static")
+    _check_all(second, x, dy, w, mu1, mu2, "hinted")
+    # offsets grow past the hinted bucket between two calls: the stale hint must not matter
+    lim = k // 2 - 0.01
+    mu1b, mu2b = mu1.copy(), mu2.copy()
+    mu1b.flat[0] = lim; mu2b.flat[-1] = -lim
+    third = _run(plan, x, dy, w, mu1b, mu2b)
+    _check_all(third, x, dy, w, mu1b, mu2b, "grown")
+    # and shrink again
+    fourth = _run(plan, x, dy, w, mu1, mu2, calls=2)
+    for key in second:
+        assert np.array_equal(fourth[key], second[key]), key
+
+
+def test_dynamic_bucket_costs_what_the_offsets_need():
+    """A max_kernel_size=65 layer whose offsets sit within +-3 must run close to the kernel-9 time (the reference picks
+    its kernels from the actual offsets on every call, dau_conv_op.cpp:236-253)."""
+    from dau_conv import _capi
+    N, S, F, G, H, W = 16, 64, 64, 4, 56, 56
+    x, dy, w, mu1, mu2 = _inputs(32, N, S, F, G, H, W, 9, 3.0)
+    dev = lambda a: torch.from_numpy(a).cuda()
+    xd, dyd, wd, m1, m2 = dev(x), dev(dy), dev(w), dev(mu1), dev(mu2)
+    sigma = torch.full((1, S, G, F), 0.5, device="cuda")
+
+    def ms(plan, steps=6):
+        for _ in range(3):
+            plan.forward(xd, wd, m1, m2, sigma); plan.backward(xd, dyd, wd, m1, m2, sigma)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            plan.forward(xd, wd, m1, m2, sigma); plan.backward(xd, dyd, wd, m1, m2, sigma)
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / steps
+
+    t9 = ms(_capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5))
+    t65 = ms(_capi.Plan(N, S, F, G, H, W, max_kernel_size=65, sigma_hint=0.5))
+    t65s = ms(_capi.Plan(N, S, F, G, H, W, max_kernel_size=65, sigma_hint=0.5,
+                         flags=_capi.FLAG_USE_INTERPOLATION | _capi.FLAG_STATIC_BUCKET))
+    print("k=9 %.3f ms, k=65 dynamic %.3f ms, k=65 static %.3f ms" % (t9, t65, t65s))
+    assert t65 < 1.25 * t9 + 0.3, (t9, t65, t65s)          # the guarded-out static set costs a few empty launches
+    assert t65s > 1.5 * t65, (t65, t65s)

@@ -120,13 +120,60 @@ def test_layer_raises_like_the_reference_ops():
     mu = torch.zeros(1, 2, 2, 4, device="cuda")
     sigma = torch.full((1, 2, 2, 4), 0.5, device="cuda")
     bad = mu.clone(); bad[0, 0, 0, 0] = float("nan")
+    # check_offsets=True: wait for the call and raise at once, as the reference ops do
     with pytest.raises(dau_conv.FailedPreconditionError):      # dau_conv_op.cpp:256-261
-        dau_conv.dau_conv(x, w, bad, mu, sigma, num_output=4, kernel_size=9)
+        dau_conv.dau_conv(x, w, bad, mu, sigma, num_output=4, kernel_size=9, check_offsets=True)
     far = mu.clone(); far[0, 0, 0, 0] = 40.0
     with pytest.raises(dau_conv.InvalidArgumentError):         # dau_conv_op.cpp:245-248
-        dau_conv.dau_conv(x, w, far, mu, sigma, num_output=4, kernel_size=65)
+        dau_conv.dau_conv(x, w, far, mu, sigma, num_output=4, kernel_size=65, check_offsets=True)
     with pytest.raises(dau_conv.InvalidArgumentError):         # shape function: last dim == num_output
         dau_conv.dau_conv(x, w, mu, mu, sigma, num_output=8, kernel_size=9)
+
+
+def test_async_offset_check_raises_one_call_late_without_a_sync():
+    """check_offsets="async" (the default): the call with the bad offsets returns, the NEXT call of the same plan (or
+    check_pending_offsets) raises the reference's error from the status the device left in pinned host memory."""
+    import dau_conv
+    x = torch.rand(1, 2, 9, 11, device="cuda")
+    w = torch.randn(1, 2, 2, 4, device="cuda")
+    mu = torch.zeros(1, 2, 2, 4, device="cuda")
+    sigma = torch.full((1, 2, 2, 4), 0.5, device="cuda")
+    bad = mu.clone(); bad[0, 1, 0, 3] = float("nan")
+    y = dau_conv.dau_conv(x, w, bad, mu, sigma, num_output=4, kernel_size=9)        # enqueued, not checked yet
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all()                                                   # a NaN offset reads as offset 0
+    with pytest.raises(dau_conv.FailedPreconditionError):
+        dau_conv.dau_conv(x, w, mu, mu, sigma, num_output=4, kernel_size=9)         # same plan: sees the previous status
+    # a clean call clears it again
+    dau_conv.dau_conv(x, w, mu, mu, sigma, num_output=4, kernel_size=9, check_offsets=False)
+    dau_conv.check_pending_offsets()
+    far = mu.clone(); far[0, 0, 0, 0] = 6.0
+    dau_conv.dau_conv(x, w, far, mu, sigma, num_output=4, kernel_size=9)
+    with pytest.raises(dau_conv.InvalidArgumentError):
+        dau_conv.check_pending_offsets()
+    dau_conv.dau_conv(x, w, mu, mu, sigma, num_output=4, kernel_size=9, check_offsets=False)
+    dau_conv.check_pending_offsets()
+
+
+def test_sigma_host_copy_follows_the_tensor():
+    """The prefilter support comes from a host copy of sigma; it must follow load_state_dict / in-place updates
+    (the reference re-reads sigma whenever it builds its layer, base_dau_conv_layer.cpp:140-146)."""
+    import dau_conv
+    from oracle import dau_oracle as orc
+    torch.manual_seed(0)
+    layer = dau_conv.DAUConv2d(filters=4, dau_units=(1, 2), max_kernel_size=9, use_bias=False, in_channels=3).cuda()
+    x = torch.rand(2, 3, 12, 12, device="cuda")
+    layer(x)
+    assert layer._sigma_host == 0.5
+    sd = layer.state_dict(); sd["sigma"] = torch.tensor([0.8], device="cuda")
+    layer.load_state_dict(sd)
+    y = layer(x)
+    assert abs(layer._sigma_host - 0.8) < 1e-6
+    m = layer._dau_convolution_op.mean_max_allowed_offset
+    want = orc.forward(x.cpu().numpy(), layer.weights.detach().cpu().numpy(),
+                       layer.mu1.detach().clamp(-m, m).cpu().numpy(), layer.mu2.detach().clamp(-m, m).cpu().numpy(), 0.8)
+    from util import assert_parity
+    assert_parity(y.detach().cpu().numpy(), want, "y after sigma 0.5 -> 0.8")      # 9x9 prefilter, not a truncated 7x7
 
 
 def test_toy_training_loop_reduces_the_loss():
