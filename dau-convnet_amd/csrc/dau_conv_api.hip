@@ -139,6 +139,12 @@ struct Candidate {
     Guard guard;
 };
 
+void clear_host_status(const dau_conv_plan* p) {
+    if (!p->host_status) return;
+    volatile unsigned* h = reinterpret_cast<volatile unsigned*>(p->host_status);
+    h[2] = 0u; h[1] = 0u; h[0] = 0u;
+}
+
 // pass_kind: 0 = gather-sum (needs fwd_ok), 1 = gather-dot (needs dot_ok)
 int pick_candidates(const dau_conv_plan* p, const Status* dev_status, int pass_kind, Candidate out[2]) {
     const BucketSet* top = &p->top();
@@ -160,13 +166,21 @@ int pick_candidates(const dau_conv_plan* p, const Status* dev_status, int pass_k
     return 1;
 }
 
-void ensure_attrs(const dau_conv_plan* p) {
-    if (p->attrs_set) return;
+// first call of a plan: raise the dynamic-LDS limit of every kernel its sets can launch (per device, hence not at plan
+// creation, which must also work without a device)
+int ensure_attrs(const dau_conv_plan* p) {
+    if (p->attrs_set) return DAU_OK;
+    (void)hipGetLastError();
     for (int i = 0; i < p->nsets; ++i) {
         if (p->sets[i].fwd_ok) { tiled_gather_init(p->sets[i].tiled_fwd); tiled_gather_init(p->sets[i].tiled_dx); }
         if (p->sets[i].dot_ok) tiled_dot_init(p->sets[i].tiled_dot);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+            return fail(DAU_INTERNAL, "raising the dynamic-LDS limit of the bucket-%d kernels failed: %s", p->sets[i].bucket,
+                        hipGetErrorString(e));
     }
     p->attrs_set = true;
+    return DAU_OK;
 }
 
 struct FwdWs {
@@ -394,7 +408,7 @@ int dau_conv_forward(const dau_conv_plan* p, void* stream, const float* x, const
         return fail(DAU_INVALID_ARGUMENT, "workspace too small: %zu < %zu", workspace_bytes, ws.bytes);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Shape& s = p->sh;
-    ensure_attrs(p);
+    if (int rc = ensure_attrs(p)) return rc;
     DAU_HIP(hipMemsetAsync(ws.status, 0, sizeof(Status), st));
     launch_synth_filters(st, sigma, p->blur_k, p->d.flags, ws.filters);
     launch_prepare_units(st, w, mu1, mu2, s, p->d.number_units_ignore, p->d.flags, p->bucket, false, ws.table, ws.status,
@@ -470,7 +484,7 @@ int dau_conv_backward(const dau_conv_plan* p, void* stream, const float* x, cons
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Shape& s = p->sh;
     const int flags = p->d.flags;
-    ensure_attrs(p);
+    if (int rc = ensure_attrs(p)) return rc;
     DAU_HIP(hipMemsetAsync(ws.status, 0, sizeof(Status), st));
     launch_synth_filters(st, sigma, p->blur_k, flags, ws.filters);
 
@@ -515,7 +529,7 @@ int dau_conv_backward_param_sums(const dau_conv_plan* p, void* stream, const flo
     BwdWs ws;
     if (int rc = check_backward_ws(p, workspace, workspace_bytes, &ws)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    ensure_attrs(p);
+    if (int rc = ensure_attrs(p)) return rc;
     DAU_HIP(hipMemsetAsync(ws.status, 0, sizeof(Status), st));
     launch_synth_filters(st, sigma, p->blur_k, p->d.flags, ws.filters);
     run_param_sums(p, st, x, dy, mu1, mu2, ws, sums_out);
@@ -544,6 +558,7 @@ int dau_conv_check_status(const dau_conv_plan* p, void* stream, const void* work
     float mx;
     std::memcpy(&mx, &h.max_abs_mu_bits, sizeof(float));
     if (max_abs_mu_out) *max_abs_mu_out = mx;
+    if (h.nan_seen || mx > (float)p->bucket) clear_host_status(p);   // reported here: dau_conv_last_status stays quiet about it
     if (h.nan_seen) return fail(DAU_FAILED_PRECONDITION, "DAUConvOp ERROR: got NaN value in offset (mu1,mu2) variable");
     if (mx > (float)p->bucket)
         return fail(DAU_INVALID_ARGUMENT,
@@ -565,6 +580,8 @@ int dau_conv_last_status(const dau_conv_plan* p, float* max_abs_mu_out, int32_t*
     std::memcpy(&mx, &bits, sizeof(float));
     if (max_abs_mu_out) *max_abs_mu_out = mx;
     if (valid_out) *valid_out = 1;
+    // a bad status is reported once: the mirror goes back to "nothing reported" until the next call completes
+    if (nan_seen || mx > (float)p->bucket) clear_host_status(p);
     if (nan_seen) return fail(DAU_FAILED_PRECONDITION, "DAUConvOp ERROR: got NaN value in offset (mu1,mu2) variable");
     if (mx > (float)p->bucket)
         return fail(DAU_INVALID_ARGUMENT,

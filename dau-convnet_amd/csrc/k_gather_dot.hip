@@ -516,8 +516,15 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
         first_act = AS;
 #pragma unroll
         for (int si = AS - 1; si >= 0; --si) first_act = act[si] ? si : first_act;
-        // this slot pair is empty for the whole (window, channel block, 64 input channels): nothing to do
-        if (!__syncthreads_or(first_act < AS ? 1 : 0)) return;
+        // this slot pair is empty for the whole (window, channel block, 64 input channels): nothing to do.  (The flag
+        // lives behind the error tiles in the dynamic LDS: __syncthreads_or would add static LDS on top of a tile that
+        // already takes all but 3 KiB of the 160.)
+        volatile unsigned* any_unit = reinterpret_cast<volatile unsigned*>(smem + (size_t)a.nbuf * a.tile_bytes);
+        if (threadIdx.x == 0) *any_unit = 0u;
+        __syncthreads();
+        if (lane == 0 && first_act < AS) *any_unit = 1u;
+        __syncthreads();
+        if (*any_unit == 0u) return;
     }
     const bool wave_idle = first_act >= AS;
 
@@ -850,7 +857,7 @@ bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, int igno
     const bool as1 = getenv("DAU_DOT_AS1") != nullptr;
     const bool one_tile = getenv("DAU_DOT_NBUF") && atoi(getenv("DAU_DOT_NBUF")) == 1;
     const DotGeometry g = make_dot_geometry(sh, R, as1, one_tile);
-    if (g.tile_bytes > 160 * 1024) return false;
+    if (g.nbuf * g.tile_bytes + 16 > 160 * 1024) return false;
     // immediates of the unrolled column walk must fit 16 bits
     if ((size_t)g.epitch * kDF * 8 + (kRW + 1) * kDF * 8 > 65535) return false;
     {
@@ -944,7 +951,7 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
     a.debug = c.debug;
     a.guard = guard;
     const bool binned = g.nsub1 > 1;
-    const size_t lds = (size_t)g.nbuf * g.tile_bytes;
+    const size_t lds = (size_t)g.nbuf * g.tile_bytes + 16;   // + the "any unit" word of the binned kernel
     for (int i = 0; i < g.npass; ++i) {           // every pass writes its own units' slabs of the partial sums
         const DotGeometry::Pass& ps = g.pass[i];
         a.params = reinterpret_cast<const float*>(ws + l.params_off + ps.params_off);

@@ -51,13 +51,13 @@ def _run(plan, x, dy, w, mu1, mu2, dtype=torch.float32, calls=1):
                 dmu2=g[3].cpu().numpy(), dsigma=g[4].cpu().numpy())
 
 
-def _check_all(got, x, dy, w, mu1, mu2, name, ignore=0, io_rel=1e-4, io_floor=1e-6):
+def _check_all(got, x, dy, w, mu1, mu2, name, ignore=0, io_rel=1e-4, io_floor=1e-6, param_floor=1e-6):
     want_y = orc.forward(x, w, mu1, mu2, 0.5, ignore=ignore)
     want = orc.backward(x, dy, w, mu1, mu2, 0.5, ignore=ignore)
     assert_parity(got["y"], want_y, name + "/y", rel=io_rel, floor=io_floor)
     assert_parity(got["dx"], want["dx"], name + "/dx", rel=io_rel, floor=io_floor)
     for key in ("dw", "dmu1", "dmu2", "dsigma"):
-        assert_parity(got[key], want[key], name + "/" + key)
+        assert_parity(got[key], want[key], name + "/" + key, floor=param_floor)
 
 
 def test_ns_channel_counts_all_six_tensors():
@@ -67,7 +67,12 @@ def test_ns_channel_counts_all_six_tensors():
     x, dy, w, mu1, mu2 = _inputs(21, N, S, F, G, H, W, k, 3.0)
     plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, sigma_hint=0.5)
     assert plan.info["algo_forward"] == _capi.ALGO_TILED and plan.info["algo_backward"] == _capi.ALGO_TILED
-    _check_all(_run(plan, x, dy, w, mu1, mu2), x, dy, w, mu1, mu2, "NS")
+    # Each parameter gradient here is a sum of N*H*W = 100 352 signed products whose partial sums wander up to ~600.  The
+    # oracle accumulates in double; the kernel keeps 32 fp32 chains per unit (16 chunks x 2 images, summed in double
+    # afterwards), whose rounding adds up to ~1.1e-6 of the tensor's max-norm (measured).  Floor for these four tensors:
+    # 3e-6 of the max-norm -- the same floor the golden-vector tests grant the numpy oracle's own float32 sums; the
+    # 1e-4 relative bar is unchanged, and y / dx (4096-term sums) keep the 1e-6 floor.
+    _check_all(_run(plan, x, dy, w, mu1, mu2), x, dy, w, mu1, mu2, "NS", param_floor=3e-6)
 
 
 def test_c1_alexnet_conv2_full_size():
