@@ -74,8 +74,8 @@ struct BucketSet {
     TiledConfig tiled_dx;    // gather-sum dx : F -> S
     TiledDotConfig tiled_dot;
 };
-constexpr int kBuckets[] = {4, 8, 16, 24, 32};
-constexpr int kNumBuckets = 5;
+constexpr int kBuckets[] = {4, 8, 16, 20, 24, 32};
+constexpr int kNumBuckets = 6;
 
 struct dau_conv_plan {
     dau_conv_desc d;
@@ -277,6 +277,7 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
     if (half <= 4) bucket = 4;
     else if (half <= 8) bucket = 8;
     else if (half <= 16) bucket = 16;
+    else if (half <= 20) bucket = 20;
     else if (half <= 24) bucket = 24;
     else if (half <= 32) bucket = 32;
     else

@@ -68,6 +68,7 @@ struct DotGeometry {
     int npass;
     Pass pass[2];
     int nbuf;                   // error tiles resident in LDS: 2 (load under compute) or 1 (R = 8: one tile fills the LDS)
+    int Rp;                     // the bucket rounded up to whole windows (R = 20 is staged and binned like R = 24)
     int Rt;                     // offset radius one LDS tile covers: min(R, 8)
     int nsub1;                  // R > 8: the offset range is cut into nsub1 x nsub1 windows of radius Rt; one workgroup
                                 // pass per window, units outside the window contribute zero (their factors are zeroed)
@@ -80,7 +81,9 @@ struct DotGeometry {
 DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one_tile = false) {
     DotGeometry g{};
     g.Rt = R < 8 ? R : 8;
-    g.nsub1 = R / g.Rt;
+    g.nsub1 = (R + g.Rt - 1) / g.Rt;
+    g.Rp = g.nsub1 * g.Rt;
+    R = g.Rp;
     const bool binned = g.nsub1 > 1;
     g.epitch = kRW + 2 * g.Rt + 1;
     // rows per region: 7 when that pads the height less (7, 14, 21, 27, 28, ...)
@@ -895,7 +898,7 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
         const int cwmax = s.W < kPackErrorChunk ? s.W : kPackErrorChunk;
         const size_t lds = (size_t)64 * (cwmax | 1) * 4;
         const int nxc = (g.EX + kPackErrorChunk - 1) / kPackErrorChunk;
-        hipLaunchKernelGGL(pack_error_kernel, dim3(c.NP * g.nfb * g.EY * nxc), dim3(256), lds, st, dy, s.N, s.F, s.H, s.W, c.R, g.EX,
+        hipLaunchKernelGGL(pack_error_kernel, dim3(c.NP * g.nfb * g.EY * nxc), dim3(256), lds, st, dy, s.N, s.F, s.H, s.W, g.Rp, g.EX,
                            g.EY, g.nfb, drop_col, drop_row, c.bf16 ? 1 : 0, reinterpret_cast<float*>(ws + l.ep_off), guard);
     }
     {
@@ -920,7 +923,7 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
         const DotGeometry::Pass& ps = g.pass[0];
         const long total = (long)g.nsub1 * g.nsub1 * s_pad * g.nfb * kDF;
         const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL(dot_params_binned_kernel, dim3(grid), dim3(256), 0, st, table_bare, s.S, s.G, s.F, c.R, g.Rt, g.nsub1,
+        hipLaunchKernelGGL(dot_params_binned_kernel, dim3(grid), dim3(256), 0, st, table_bare, s.S, s.G, s.F, g.Rp, g.Rt, g.nsub1,
                            g.epitch, ps.ngb, g.nfb, s_pad, reinterpret_cast<float*>(ws + l.params_off + ps.params_off), guard);
         return;
     }
@@ -928,7 +931,7 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
         const DotGeometry::Pass& ps = g.pass[i];
         const long total = (long)g.nsub1 * g.nsub1 * s_pad * ps.ngb * ps.GP * g.nfb * 64;
         const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL(dot_params_kernel, dim3(grid), dim3(256), 0, st, table_bare, s.S, s.G, s.F, c.R, g.Rt, g.nsub1,
+        hipLaunchKernelGGL(dot_params_kernel, dim3(grid), dim3(256), 0, st, table_bare, s.S, s.G, s.F, g.Rp, g.Rt, g.nsub1,
                            g.epitch, ps.g_begin, ps.GP, ps.ngb, g.nfb, s_pad,
                            reinterpret_cast<float*>(ws + l.params_off + ps.params_off), guard);
     }
@@ -943,7 +946,7 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
     a.ep = ws + l.ep_off;
     a.xk = reinterpret_cast<const float*>(ws + l.xk_off);
     a.partial = reinterpret_cast<float*>(ws + l.partial_off);
-    a.N = s.N; a.S = s.S; a.F = s.F; a.G = s.G; a.R = c.R;
+    a.N = s.N; a.S = s.S; a.F = s.F; a.G = s.G; a.R = g.Rp;
     a.NP = c.NP; a.nfb = g.nfb; a.nbuf = g.nbuf; a.Rt = g.Rt; a.nsub1 = g.nsub1; a.chunks = g.chunks; a.items = g.items;
     a.rx = g.rx; a.ry = g.ry; a.EX = g.EX; a.EY = g.EY; a.Hp = g.Hp; a.Wp = g.Wp; a.epitch = g.epitch; a.erows = g.erows;
     a.s_pad = g.s_pad;

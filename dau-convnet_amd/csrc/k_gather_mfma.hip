@@ -45,7 +45,9 @@ inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // An image is cut into patches of ph x pw pixels; every patch is gathered by one workgroup pass from its own staged
 // plane (the patch plus a border of R on the left/top and R+1 on the right/bottom, taken from the neighbouring pixels of
 // the blurred image, zero outside it).  EDGE variants have ph = 8*ty, pw = 8*tx whatever H and W are (pixels beyond the
-// image are computed and dropped at the store); the one non-EDGE variant covers a whole 25..31 pixel image.
+// image are computed and dropped at the store) and two extra "edge" tiles for the last row / column of Z; non-EDGE
+// variants have patches of at most 8*ty - 1 by 8*tx - 1 pixels (a whole image when it is that small), whose
+// (ph+1) x (pw+1) domain of Z fits the regular tiles.
 struct Geometry {
     int H, W, R;              // image, offset bucket
     int Rt;                   // offset radius one staged plane covers: R for R <= 16, R/2 for R = 24, 32
@@ -87,6 +89,11 @@ const Variant kVariants[] = {
     {3, 3, 40, 0, 1, 2, 10240, 8, 0},   // 13: 2 x one 17..23 pixel image, 8 channels
     {2, 2, 40, 0, 1, 4, 8192, 8, 0},    // 14: 4 x one 9..15 pixel image (14x14), 8 channels
     {1, 1, 40, 0, 1, 8, 5120, 16, 0},   // 15: 8 x one <=7 pixel image (7x7), 16 channels
+    // Large offsets on large images: edge-free 31 pixel patches (the 32 x 32 domain of Z is the 4 x 4 regular tiles, so
+    // no strip, and the plane is just (32 + 2R)^2 positions): R <= 20 under pitch 72, R <= 28 under pitch 104 with eight
+    // output channels per workgroup sharing the bigger plane.  Bucket 24 therefore needs no offset windows.
+    {4, 4, 72, 0, 2, 1, 0, 4, 0},       // 16: 31 pixel patches, R <= 20
+    {4, 4, 104, 0, 1, 1, 0, 8, 0},      // 17: 31 pixel patches, R <= 28, 8 channels
 };
 
 // one (channel block, input channel) slice of the packed unit table: [G slots][fb channels][8 dwords]; window passes
@@ -98,7 +105,11 @@ size_t ut_stride_bytes(int G, int fb, bool binned) { return round_up((size_t)G *
 Geometry make_geometry(int H, int W, int R, int G, int N, int Cout, int only = -1) {
     Geometry g{};
     g.H = H; g.W = W; g.R = R; g.variant = -1;
-    g.nwin1 = (R + 15) / 16; g.Rt = R / g.nwin1;
+    // offset windows only where no instantiated kernel can stage the whole bucket around a patch (R = 32 today)
+    const int Rfull = R;
+    for (int nwin1 = 1; nwin1 <= 2 && g.variant < 0; ++nwin1) {
+    if (Rfull % nwin1) continue;
+    g.nwin1 = nwin1; g.Rt = Rfull / nwin1;
     const bool binned = g.nwin1 > 1;
     R = g.Rt;                                                // everything below sizes ONE plane
     // The environment is consulted at plan creation only (only < 0); afterwards the plan's row is passed in.
@@ -121,9 +132,8 @@ Geometry make_geometry(int H, int W, int R, int G, int N, int Cout, int only = -
             ph = v.ty * 8; pw = v.tx * 8;
             cols = pw + 1 + 2 * R; rows = ph + 1 + 2 * R;
         } else {
-            // whole image in one patch, regular tiles cover the (H+1) x (W+1) domain of Z
-            if ((W + 1 + 7) / 8 > v.tx || (H + 1 + 7) / 8 > v.ty) continue;
-            ph = H; pw = W;
+            // regular tiles cover the (ph+1) x (pw+1) domain of Z: a whole image, or patches of 8*t - 1 pixels
+            ph = H < v.ty * 8 - 1 ? H : v.ty * 8 - 1; pw = W < v.tx * 8 - 1 ? W : v.tx * 8 - 1;
             cols = v.tx * 8 + 2 * R; rows = v.ty * 8 + 2 * R;
         }
         if (cols > v.pitch) continue;
@@ -148,7 +158,9 @@ Geometry make_geometry(int H, int W, int R, int G, int N, int Cout, int only = -
         g.variant = i; g.ph = ph; g.pw = pw; g.npx = npx; g.npy = npy; g.rows = rows; g.cols = cols; g.pitch = v.pitch;
         g.tx = v.tx; g.ty = v.ty; g.edge = v.edge; g.sk = v.sk; g.fb = v.fb;
     }
+    }
     if (g.variant < 0) return g;
+    R = g.Rt;
     g.strip_pitch = g.rows;
     g.strip_off = (size_t)g.rows * g.pitch * 8;
     g.plane_bytes = round_up(g.strip_off + (g.edge ? (size_t)(2 * R + 1) * g.strip_pitch * 8 : 0), 1024);
@@ -350,6 +362,7 @@ struct GatherArgs {
     float* out;                // [N][Cout][H][W]
     int N, Cin, Cout, G, H, W, R;
     int npx, npy;              // patches per image (EDGE variants: 8*TY x 8*TX pixels each)
+    int ph, pw;                // patch size in pixels (non-EDGE variants: at most 8*TY - 1 by 8*TX - 1)
     int nfb;                   // ceil(Cout / kFB)
     unsigned plane_bytes, ut_stride;
     unsigned strip_off;        // byte offset of the transposed strip inside a plane
@@ -513,8 +526,8 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
     const int npatch = a.npx * a.npy;
     const int npp_total = ((a.N + 1) / 2) * npatch;
 
-    // H, W: the domain one plane covers (a patch; the whole image for the non-EDGE variant)
-    const int R = a.R, H = EDGE ? TY * 8 : a.H, W = EDGE ? TX * 8 : a.W;
+    // H, W: the pixels one plane covers (a patch; the whole image when it is small enough)
+    const int R = a.R, H = EDGE ? TY * 8 : a.ph, W = EDGE ? TX * 8 : a.pw;
     const int ly = lane >> 3, lx = lane & 7;
     const unsigned lane_base = (unsigned)(((ly + R) * PITCH + (lx + R)) * 8);
     // Edge tiles (the extra row / column of Z): tile E0 = the row y = H, x = 0..W-1, read from the plane (consecutive
@@ -574,7 +587,53 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();   // plane c is in LDS for everyone; everyone is done reading plane c-1
 #endif
+#ifdef DAU_DIAG_FUSED_BLUR
+        // Timing diagnosis (results are garbage): what filling plane c+1 INSIDE this kernel would add to a wave's
+        // instruction stream (the reference's TODO base_dau_conv_layer.hpp:160-165) -- a LOWER bound:
+        // the unit slice still arrives by DMA, the plane does not; instead every wave runs the irreducible instruction mix
+        // of its 1/8 share of a separable 7+7 tap prefilter of the 71 x 71 raw window of an image pair: raw loads ->
+        // LDS, per output position and pass 7 packed FMAs, with register blocking of four outputs per lane 2.5 LDS reads,
+        // one LDS write.  No address arithmetic, no border handling, no waits beyond one for the raw loads.
+        if (c + 1 < a.Cin) {
+            const char* us = src_units + (size_t)(c + 1) * ut_stride;
+            for (unsigned piece = wave; piece < (ut_stride >> 10); piece += T::kWaves)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(us + (size_t)piece * 1024 + lane * 16),
+                                                 (lds_ptr_t)(smem + ut_base + (buf ^ 1) * ut_stride + piece * 1024), 16, 0, 0);
+            constexpr int kRawRounds = (71 * 71 + 64 * T::kWaves - 1) / (64 * T::kWaves);       // positions per lane, raw window
+            constexpr int kOutRounds = (65 * 65 + 64 * T::kWaves - 1) / (64 * T::kWaves);       // positions per lane, staged plane
+            const unsigned wr = (buf ^ 1) * buf_bytes + lane * 8, rd = buf * buf_bytes + lane * 8;
+            const char* gsrc = a.staged + (size_t)lane * 4;
+            f2 raw[kRawRounds];
+#pragma unroll
+            for (int r = 0; r < kRawRounds; ++r) {
+                asm volatile("global_load_dword %0, %2, off offset:%3\n\tglobal_load_dword %1, %2, off offset:%4"
+                             : "=&v"(raw[r].x), "=&v"(raw[r].y) : "v"(gsrc), "n"((r * 512) % 4096), "n"((r * 512 + 256) % 4096) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int r = 0; r < kRawRounds; ++r)
+                asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(wr), "v"(raw[r]), "n"(r * 512) : "memory");
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int r = 0; r < kOutRounds; r += 4) {            // four output positions per lane share ten reads
+                    f2 in[10];
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(in[i]) : "v"(rd), "n"((r * 10 + i) * 512 % 32768) : "memory");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        f2 acc = in[o];
+#pragma unroll
+                        for (int t = 0; t < 7; ++t) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(in[o + t < 10 ? o + t : 9]), "v"(in[t]));
+                        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(wr), "v"(acc), "n"(((pass * kOutRounds + r + o) * 512) % 32768) : "memory");
+                    }
+                }
+            }
+        }
+#else
         if (c + 1 < a.Cin && !((a.debug & 1) && c >= 1)) issue(c + 1, buf ^ 1);
+#endif
         const unsigned pbase = buf * buf_bytes;
         const unsigned ut_addr = ut_base + buf * ut_stride + (fi * kUnitDwords + (lane & 3) * 2) * 4;
         constexpr unsigned unit_pitch = T::FB * kUnitDwords * 4;
@@ -636,7 +695,7 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
                 const int f = fb * T::FB + fh * T::kEpiF + fl;
                 const int npp = npp0 + k;
                 const int n = 2 * (npp / npatch) + img, patch = npp % npatch;
-                const int gy = (patch / a.npx) * H + y, gx = (patch % a.npx) * W + x;    // non-EDGE: one patch, origin 0
+                const int gy = (patch / a.npx) * H + y, gx = (patch % a.npx) * W + x;
                 const float* zf = zs + (size_t)kf * zchan + (unsigned)y * zpitch + x;
                 const float v = zf[0] + zf[zplane + 1] + zf[2 * zplane + zpitch] + zf[3 * zplane + zpitch + 1];
                 if (npp < npp_total && n < a.N && f < a.Cout && gy < a.H && gx < a.W)
@@ -691,6 +750,8 @@ void dispatch_variant(int variant, hipStream_t st, const GatherArgs* a, int grid
         case 13: launch_variant<GatherTraits<3, 3, 40, false, 1, 2, 10240, 8>>(st, a, grid, lds); break;
         case 14: launch_variant<GatherTraits<2, 2, 40, false, 1, 4, 8192, 8>>(st, a, grid, lds); break;
         case 15: launch_variant<GatherTraits<1, 1, 40, false, 1, 8, 5120, 16>>(st, a, grid, lds); break;
+        case 16: launch_variant<GatherTraits<4, 4, 72, false, 2>>(st, a, grid, lds); break;
+        case 17: launch_variant<GatherTraits<4, 4, 104, false, 1, 1, 0, 8>>(st, a, grid, lds); break;
         default: break;
     }
 }
@@ -809,7 +870,7 @@ void tiled_gather_run(hipStream_t st, const TiledConfig& c, float* out, void* wo
     a.staged = static_cast<const char*>(workspace);
     a.packed = a.staged + round_up((size_t)c.NP * c.patches * c.Cin * g.plane_bytes, 256);
     a.out = out;
-    a.npx = g.npx; a.npy = g.npy;
+    a.npx = g.npx; a.npy = g.npy; a.ph = g.ph; a.pw = g.pw;
     a.N = c.N; a.Cin = c.Cin; a.Cout = c.Cout; a.G = c.G; a.H = c.H; a.W = c.W; a.R = g.Rt;
     a.accumulate = accumulate ? 1 : 0; a.bf16 = c.bf16;
     a.nfb = (c.Cout + g.fb - 1) / g.fb;

@@ -252,6 +252,14 @@ def test_seeded_shapes_against_c_oracle(shape, algo):
     dict(N=21, W=7, H=7, S=8, F=20, G=4, k=9, m=3, variant=15, stack=8, patch=8),      # 7x7 maps
     dict(N=3, W=5, H=6, S=8, F=33, G=5, k=9, m=3, variant=15, stack=8, patch=8),
     dict(N=4, W=100, H=60, S=3, F=8, G=4, k=9, m=3, variant=8, stack=2, patch=32),     # a large image cut into stacked patches
+    # edge-free 31 pixel patches for large offsets (rows 16, 17): buckets 16 / 20 / 24 / 32 without offset windows, and
+    # bucket 32 in windows of radius 16; images that are not a multiple of the patch, odd channel counts
+    dict(N=2, W=33, H=31, S=3, F=8, G=2, k=33, m=15, variant=16, stack=1, patch=32),
+    dict(N=3, W=70, H=45, S=5, F=12, G=4, k=41, m=19.5, variant=16, stack=1, patch=32),
+    dict(N=2, W=62, H=64, S=4, F=16, G=5, k=65, m=31, variant=16, stack=1, patch=32),       # windows of radius 16
+    dict(N=2, W=64, H=64, S=4, F=16, G=5, k=49, m=23.5, variant=17, stack=1, patch=32),
+    dict(N=3, W=40, H=90, S=3, F=9, G=3, k=65, m=31.5, variant=17, stack=1, patch=32),      # bucket 32 in one pass
+    dict(N=2, W=100, H=37, S=2, F=20, G=9, k=65, m=31.5, variant=17, stack=1, patch=32),    # nine units: windows
 ])
 def test_stacked_gather_variants(shape, monkeypatch):
     from dau_conv import _capi
