@@ -78,7 +78,7 @@ struct DotGeometry {
 };
 
 // as1 / one_tile: tuning choices fixed at plan creation (TiledDotConfig), so that every later call sees the same layout
-DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one_tile = false) {
+DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one_tile = false, int rounds = 0) {
     DotGeometry g{};
     g.Rt = R < 8 ? R : 8;
     g.nsub1 = (R + g.Rt - 1) / g.Rt;
@@ -131,7 +131,12 @@ DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one
         // one and a half busy slot pairs per (window, channel block) and eight rounds, so that light and heavy workgroups
         // even out
         const int per_chunk = binned ? g.nfb * g.pass[i].nsb * g.nsub1 * g.nsub1 * 3 / 2 : g.nfb * g.pass[i].nsb * g.pass[i].ngb;
-        int chunks = (256 * (binned ? 8 : 4) + (binned ? per_chunk - 1 : 0)) / per_chunk;
+        // rounds: workgroups per CU the grid is sized for.  More chunks = shorter fp32 accumulation chains (every chunk's
+        // partial sums are added in double afterwards) and a finer tail, at 16 B of partial sums per unit and chunk; at the
+        // north-star shape 4, 8 and 16 rounds take the same time (same-box A/B, profiles/r2_ab_dot_rounds.txt), and 16
+        // rounds halve the rounding error of the parameter gradients against the double-accumulating oracle.
+        const int nrounds = rounds > 0 ? rounds : (binned ? 8 : 16);
+        int chunks = (256 * nrounds + (binned ? per_chunk - 1 : 0)) / per_chunk;
         if (chunks > g.items) chunks = g.items;
         if (chunks < 1) chunks = 1;
         const int per = (g.items + chunks - 1) / chunks;
@@ -859,7 +864,8 @@ bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, int igno
     // timing experiments: DAU_DOT_AS1 (one input channel per wave), DAU_DOT_NBUF=1 (one error tile), DAU_DOT_DEBUG
     const bool as1 = getenv("DAU_DOT_AS1") != nullptr;
     const bool one_tile = getenv("DAU_DOT_NBUF") && atoi(getenv("DAU_DOT_NBUF")) == 1;
-    const DotGeometry g = make_dot_geometry(sh, R, as1, one_tile);
+    const int rounds = getenv("DAU_DOT_ROUNDS") ? atoi(getenv("DAU_DOT_ROUNDS")) : 0;
+    const DotGeometry g = make_dot_geometry(sh, R, as1, one_tile, rounds);
     if (g.nbuf * g.tile_bytes + 16 > 160 * 1024) return false;
     // immediates of the unrolled column walk must fit 16 bits
     if ((size_t)g.epitch * kDF * 8 + (kRW + 1) * kDF * 8 > 65535) return false;
@@ -871,17 +877,17 @@ bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, int igno
     TiledDotConfig c{};
     c.sh = sh; c.R = R; c.blur_k = blur_k; c.NP = (sh.N + 1) / 2; c.variant = g.npass; c.windows = g.nsub1 * g.nsub1;
     c.bf16 = bf16; c.ignore = ignore;
-    c.as1 = as1; c.one_tile = one_tile; c.debug = getenv("DAU_DOT_DEBUG") ? atoi(getenv("DAU_DOT_DEBUG")) : 0;
+    c.as1 = as1; c.one_tile = one_tile; c.rounds = rounds; c.debug = getenv("DAU_DOT_DEBUG") ? atoi(getenv("DAU_DOT_DEBUG")) : 0;
     *cfg = c;
     return true;
 }
 
 size_t tiled_dot_workspace_bytes(const TiledDotConfig& c) {
-    return dot_layout(c, make_dot_geometry(c.sh, c.R, c.as1, c.one_tile)).total;
+    return dot_layout(c, make_dot_geometry(c.sh, c.R, c.as1, c.one_tile, c.rounds)).total;
 }
 
 void tiled_dot_init(const TiledDotConfig& c) {
-    const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile);
+    const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile, c.rounds);
     for (int i = 0; i < g.npass; ++i) dispatch_dot(g.nsub1 > 1, g.RH, g.pass[i].GP, g.pass[i].AS, nullptr, nullptr, 0, 0);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pack_error_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blur4_pack_for(c.blur_k)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -889,7 +895,7 @@ void tiled_dot_init(const TiledDotConfig& c) {
 
 void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, const float* dy, const float* filters,
                        const UnitRef* table_bare, int drop_col, int drop_row, void* workspace, const Guard& guard) {
-    const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile);
+    const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile, c.rounds);
     const DotLayout l = dot_layout(c, g);
     char* ws = static_cast<char*>(workspace);
     const Shape& s = c.sh;
@@ -938,7 +944,7 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
 }
 
 void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* workspace, const Guard& guard) {
-    const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile);
+    const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile, c.rounds);
     const DotLayout l = dot_layout(c, g);
     char* ws = static_cast<char*>(workspace);
     const Shape& s = c.sh;
