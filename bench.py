@@ -136,10 +136,10 @@ def measured_traffic(workload_key, io, dominant):
         return None, "committed PMC pass is from another build of the library (stale)"
     key = {"gather_dot": "dau::gather_dot_kernel", "gather_sum_fwd": "dau::gather_mfma_kernel",
            "gather_sum_dx": "dau::gather_mfma_kernel"}.get(dominant, "")
-    hits = [v["hbm_bytes_per_pass"] for k, v in run["kernels"].items() if key and k.startswith(key)]
-    if not hits:
+    fam = run["kernels"].get(key)       # the family entry: all instantiations / window launches of one pass
+    if not fam or "hbm_bytes_per_pass" not in fam:
         return None, "dominant kernel not in the committed PMC pass"
-    return round(hits[0] / 1e9, 3), "profiles/r2_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, separate passes)"
+    return round(fam["hbm_bytes_per_pass"] / 1e9, 3), "profiles/r2_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, separate passes)"
 
 
 def main():
