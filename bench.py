@@ -72,6 +72,8 @@ def parse_args():
     ap.add_argument("--shape", default=None, help="ad-hoc workload N,S,F,H,W,G,k[,m] (overrides --workload)")
     ap.add_argument("--io", default="f32", choices=["f32", "bf16"],
                     help="storage type of x, y, dy, dx (BASELINE config 2 names bf16); arithmetic is fp32 either way")
+    ap.add_argument("--dense", action="store_true",
+                    help="with --io bf16: DAU_FLAG_DENSE_BF16 (gather-sum passes of calls with |mu| <= 4 as a densified bf16 MFMA GEMM)")
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 direct, 2 tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-layer", action="store_true", help="skip the layer-level (DAUConv2d + autograd) timing")
@@ -218,7 +220,8 @@ def main():
     if args.io == "bf16":
         x, dy = x.to(torch.bfloat16), dy.to(torch.bfloat16)
     plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, number_units_ignore=ignore, algo=args.algo,
-                      flags=_capi.FLAG_USE_INTERPOLATION | (_capi.FLAG_IO_BF16 if args.io == "bf16" else 0),
+                      flags=_capi.FLAG_USE_INTERPOLATION | (_capi.FLAG_IO_BF16 if args.io == "bf16" else 0) |
+                            (_capi.FLAG_DENSE_BF16 if args.dense else 0),
                       sigma_hint=0.5, mu_learning_rate_factor=1.0)
     from dau_conv.distributed import OverlappedBackward
     exchange = OverlappedBackward((1, S, G, F), dev) if use_dist else None
@@ -283,6 +286,7 @@ def main():
     # over the live units
     unit_px = float(G_live) * N * H * W * S * F
     flops = {"gather_sum_fwd": 8.0 * unit_px, "gather_sum_dx": 8.0 * unit_px, "gather_dot": 16.0 * unit_px}
+    dense = bool(args.dense and plan.info.get("gather_dense_bf16"))
     kern = {}
     for name, (ms, passes) in prof.items():
         if passes:
@@ -308,7 +312,7 @@ def main():
     # the same step through the drop-in layer: DAUConv2d + autograd with its default offset check ("async": the previous
     # call's status is read from pinned host memory, no sync) -- what a model built on the Python surface pays
     layer = None
-    if rank == 0 and world == 1 and not args.no_layer and ignore == 0:
+    if rank == 0 and world == 1 and not args.no_layer and ignore == 0 and not args.dense:
         import dau_conv
         torch.cuda.empty_cache()
         lay = dau_conv.DAUConv2d(filters=F, dau_units=(1, G), max_kernel_size=k, use_bias=False, in_channels=S,
@@ -369,6 +373,7 @@ def main():
                               exchange="all_reduce(sum) of raw param-grad sums [4,S,G,F] = %d floats per step, async under the dx pass; finalize after"
                               % (4 * S * G * F)) if use_dist else None),
                    config=dict(workload=wl["label"] + (" [bf16 activations in HBM]" if args.io == "bf16" else "") +
+                               (" [gather-sum passes as densified bf16 MFMA GEMM]" if dense else "") +
                                ("" if backend == "nccl" else " [REHEARSAL: %s backend, ranks share GPUs]" % backend),
                                global_batch=N * world, parallelism="dp%d" % world,
                                algo_forward=plan.info["algo_forward"], algo_backward=plan.info["algo_backward"],

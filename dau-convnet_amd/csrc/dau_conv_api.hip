@@ -73,6 +73,9 @@ struct BucketSet {
     TiledConfig tiled_fwd;   // gather-sum y  : S -> F
     TiledConfig tiled_dx;    // gather-sum dx : F -> S
     TiledDotConfig tiled_dot;
+    // DAU_FLAG_DENSE_BF16, bucket 4 only: the gather-sum passes run as a densified bf16 implicit GEMM (k_dense_bf16.hip)
+    bool dense_ok = false;
+    DenseConfig dense_fwd, dense_dx;
 };
 constexpr int kBuckets[] = {4, 8, 16, 20, 24, 32};
 constexpr int kNumBuckets = 6;
@@ -174,6 +177,7 @@ int ensure_attrs(const dau_conv_plan* p) {
     for (int i = 0; i < p->nsets; ++i) {
         if (p->sets[i].fwd_ok) { tiled_gather_init(p->sets[i].tiled_fwd); tiled_gather_init(p->sets[i].tiled_dx); }
         if (p->sets[i].dot_ok) tiled_dot_init(p->sets[i].tiled_dot);
+        if (p->sets[i].dense_ok) { dense_gather_init(p->sets[i].dense_fwd); dense_gather_init(p->sets[i].dense_dx); }
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return fail(DAU_INTERNAL, "raising the dynamic-LDS limit of the bucket-%d kernels failed: %s", p->sets[i].bucket,
@@ -200,8 +204,10 @@ FwdWs carve_forward(const dau_conv_plan* p, void* ws) {
     w.table = c.take<UnitRef>(p->units());
     if (p->algo_fwd == DAU_ALGO_TILED) {
         size_t need = 0;
-        for (int i = 0; i < p->nsets; ++i)
+        for (int i = 0; i < p->nsets; ++i) {
             if (p->sets[i].fwd_ok) need = std::max(need, tiled_gather_workspace_bytes(p->sets[i].tiled_fwd));
+            if (p->sets[i].dense_ok) need = std::max(need, dense_gather_workspace_bytes(p->sets[i].dense_fwd));
+        }
         w.tiled = c.take<char>(need);
     } else {
         w.xb = c.take<float>((size_t)p->sh.N * p->sh.S * p->sh.H * p->sh.W);
@@ -242,8 +248,10 @@ BwdWs carve_backward(const dau_conv_plan* p, void* ws) {
     }
     if (p->algo_fwd == DAU_ALGO_TILED) {
         size_t need = 0;
-        for (int i = 0; i < p->nsets; ++i)
+        for (int i = 0; i < p->nsets; ++i) {
             if (p->sets[i].fwd_ok) need = std::max(need, tiled_gather_workspace_bytes(p->sets[i].tiled_dx));
+            if (p->sets[i].dense_ok) need = std::max(need, dense_gather_workspace_bytes(p->sets[i].dense_dx));
+        }
         w.tiled_dx = c.take<char>(need);
     } else {
         w.eb = c.take<float>((size_t)s.N * s.F * s.H * s.W);
@@ -310,6 +318,13 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
         bs.fwd_ok = tiled_gather_configure(s.N, s.S, s.F, s.G, s.H, s.W, b, blur_k, bf16, &bs.tiled_fwd) &&
                     tiled_gather_configure(s.N, s.F, s.S, s.G, s.H, s.W, b, blur_k, bf16, &bs.tiled_dx);
         bs.dot_ok = tiled_dot_configure(s, b, blur_k, bf16, desc->number_units_ignore, &bs.tiled_dot);
+        bs.dense_ok = (desc->flags & DAU_FLAG_DENSE_BF16) && bs.fwd_ok && desc->algo != DAU_ALGO_DIRECT &&
+                      dense_gather_configure(s.N, s.S, s.F, s.G, s.H, s.W, b, blur_k, bf16, &bs.dense_fwd) &&
+                      dense_gather_configure(s.N, s.F, s.S, s.G, s.H, s.W, b, blur_k, bf16, &bs.dense_dx);
+    }
+    if ((desc->flags & DAU_FLAG_DENSE_BF16) && !bf16) {
+        delete p;
+        return fail(DAU_INVALID_ARGUMENT, "DAU_FLAG_DENSE_BF16 needs DAU_FLAG_IO_BF16 (it is the bf16 layer's gather-sum)");
     }
     const bool fwd_ok = p->top().fwd_ok, dot_ok = p->top().dot_ok;
     if (bf16 && (desc->algo == DAU_ALGO_DIRECT || !(fwd_ok && dot_ok))) {
@@ -390,6 +405,7 @@ int dau_conv_plan_get_info(const dau_conv_plan* plan, dau_conv_plan_info* info) 
     info->dot_windows = plan->algo_bwd == DAU_ALGO_TILED ? plan->top().tiled_dot.windows : 0;
     info->gather_windows = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.windows : 0;
     info->bucket_sets = plan->dynamic ? plan->nsets : 1;
+    info->gather_dense_bf16 = plan->sets[0].dense_ok ? 1 : 0;
     return DAU_OK;
 }
 
@@ -419,6 +435,12 @@ int dau_conv_forward(const dau_conv_plan* p, void* stream, const float* x, const
         const int ncand = pick_candidates(p, ws.status, 0, cand);
         if (p->profiling) ++p->prof_passes[0];
         for (int ci = 0; ci < ncand; ++ci) {
+            if (cand[ci].set->dense_ok) {                                  // bf16 layer, offsets within +-4: dense implicit GEMM
+                dense_gather_prepare(st, cand[ci].set->dense_fwd, x, ws.filters, false, ws.table, ws.tiled, cand[ci].guard);
+                ProfScope prof(p, 0, st);
+                dense_gather_run(st, cand[ci].set->dense_fwd, y, ws.tiled, cand[ci].guard);
+                continue;
+            }
             const TiledConfig& cfg = cand[ci].set->tiled_fwd;
             for (int window = 0; window < tiled_gather_windows(cfg); ++window) {   // one pass unless the bucket is 24 or 32
                 tiled_gather_prepare(st, cfg, x, ws.filters, false, ws.table, ws.tiled, window, cand[ci].guard);
@@ -506,6 +528,12 @@ int dau_conv_backward(const dau_conv_plan* p, void* stream, const float* x, cons
             Candidate cand[2];
             const int ncand = pick_candidates(p, ws.status, 0, cand);
             for (int ci = 0; ci < ncand; ++ci) {
+                if (cand[ci].set->dense_ok) {
+                    dense_gather_prepare(st, cand[ci].set->dense_dx, dy, ws.filters, true, ws.table_t, ws.tiled_dx, cand[ci].guard);
+                    ProfScope prof(p, 1, st);
+                    dense_gather_run(st, cand[ci].set->dense_dx, dx, ws.tiled_dx, cand[ci].guard);
+                    continue;
+                }
                 const TiledConfig& cfg = cand[ci].set->tiled_dx;
                 for (int window = 0; window < tiled_gather_windows(cfg); ++window) {
                     tiled_gather_prepare(st, cfg, dy, ws.filters, true, ws.table_t, ws.tiled_dx, window, cand[ci].guard);

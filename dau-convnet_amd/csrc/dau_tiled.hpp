@@ -39,6 +39,22 @@ void tiled_gather_run(hipStream_t st, const TiledConfig& cfg, float* out, void* 
 // once per plan and device, before the first run: raises the kernels' dynamic-LDS limit
 void tiled_gather_init(const TiledConfig& cfg);
 
+// Densified bf16 gather-sum (k_dense_bf16.hip; DAU_FLAG_DENSE_BF16, offset bucket 4, bfloat16 activations): the units of
+// every (input, output) channel pair scattered into a dense 10 x 10 kernel, implicit GEMM on the bf16 matrix cores.
+struct DenseConfig {
+    int N, Cin, Cout, G, H, W;
+    int R, blur_k;
+    int bf16;         // activations in and out are bfloat16 (required)
+    int nsub;         // 8-pixel subtiles per column block = kernel instantiation
+};
+bool dense_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, bool bf16, DenseConfig* cfg);
+size_t dense_gather_workspace_bytes(const DenseConfig& cfg);
+void dense_gather_init(const DenseConfig& cfg);
+// prepare: dense kernel synthesis from the unit table ([Cin][G][Cout]) + blurred bf16 staging of `in`; run: the GEMM
+void dense_gather_prepare(hipStream_t st, const DenseConfig& cfg, const float* in, const float* filters, bool mirrored,
+                          const UnitRef* table, void* workspace, const Guard& guard);
+void dense_gather_run(hipStream_t st, const DenseConfig& cfg, float* out, void* workspace, const Guard& guard);
+
 struct TiledDotConfig {
     Shape sh;
     int R, blur_k;

@@ -1,0 +1,442 @@
+// Densified gather-sum on the bf16 matrix cores (DAU_FLAG_DENSE_BF16; offsets within +-4 only).
+//
+//   out[n,f,y,x] = sum_{c} sum_{ty,tx < 10} Wd[f][c][ty][tx] * Xb[n,c, y+ty-4, x+tx-4]
+//
+// The G units of every (input channel c, output channel f) pair are scattered into a dense 10 x 10 kernel
+// (integer offsets -4..4 plus the second bilinear tap: Wd[f][c][oy+dy+4][ox+dx+4] += w * b_dydx) and the pass becomes an
+// implicit GEMM  M = output channels, N = pixels, K = input channels x 100 taps  on v_mfma_f32_32x32x16_bf16 (fp32
+// accumulation).  That is 100 / (4 G) times the FLOPs of the exact gather (k_gather_mfma.hip) at 16 x its matrix rate:
+// SURVEY.md section 7 hard part (A), measured with the library convolution in tools/probe_densified_bf16.py (1.9 - 2.7 x
+// faster than the gather for the forward pass of BASELINE config 2).  It replaces the same reference code as the gather:
+// DAUConv_forward_pipeline_kernel + interleave_input_data_kernel + perpare_weights_and_offsets
+// (include/dau_conv/dau_conv_impl/dau_conv_forward_core.hpp:804-1605, 1607-1732, 1858-2215) and caffe_gpu_convolve2
+// (src/dau_conv/util/convolve.cu:48-131).  Numerics: taps and blurred activations are rounded to bfloat16, products are
+// exact, sums are fp32 -- inside the 2e-2 bar of the bf16 configuration, not the 1e-4 bar of the fp32 one, hence opt-in
+// and only together with DAU_FLAG_IO_BF16.
+//
+// Layouts (HBM):
+//   XD[n][chunk][half][Hs][Ws][8]  bf16: Gaussian-blurred input, 16 input channels per chunk as two halves of 8 (one
+//       16-byte unit per position and half = the B fragment of one lane), staged position (r, c) = image (r-4, c-4),
+//       zero outside the image; Hs, Ws cover whole row / column blocks plus the 9-position tap border.
+//   WD[chunk][tap][CoutP][16]      bf16: the dense kernel, 32 bytes per output channel (A fragments of the two lane halves).
+// Workgroup = 4 waves = 2 (64 output channels each) x 2 (4 rows each): 128 output channels x 8 rows x NSUB*8 columns;
+// a wave owns 2 x NSUB accumulator tiles of 32 channels x (4 rows x 8 columns).  Per chunk the 17 x (NSUB*8+9) window of
+// both halves sits in LDS (pitch = 8 mod 16 positions: the four rows of a B fragment fall on different banks); per tap a
+// wave loads two A fragments from global memory (L1/L2 resident: 8 KB per tap and chunk for 256 channels) and NSUB B
+// fragments with ds_read_b128 at the tap's displacement, and issues 2*NSUB MFMAs.
+#include <cstdlib>
+
+#include "dau_tiled.hpp"
+
+namespace dau {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+namespace {
+
+constexpr int kDR = 4;                  // offset radius of the dense form
+constexpr int kDK = 2 * kDR + 2;        // taps per axis
+constexpr int kDTaps = kDK * kDK;
+constexpr int kDRows = 8;               // output rows per workgroup
+constexpr int kDFB = 128;               // output channels per workgroup
+
+inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct DenseGeom {
+    int nsub;                // 8-pixel subtiles per column block (kernel instantiation): 2, 4, 7 or 8
+    int ncb, nrb;            // column / row blocks per image
+    int Hs, Ws;              // staged plane (positions)
+    int nchunk, CoutP;
+    size_t xd_bytes, wd_bytes;
+};
+
+DenseGeom dense_geometry(const DenseConfig& c) {
+    DenseGeom g{};
+    const int sub = (c.W + 7) / 8;
+    // fewest wasted columns first, then fewest blocks
+    int best = -1; long best_cost = 0;
+    for (int ns : {2, 4, 7, 8}) {
+        const int ncb = (sub + ns - 1) / ns;
+        const long cost = (long)ncb * ns * 1000 + ncb;
+        if (best < 0 || cost < best_cost) { best = ns; best_cost = cost; }
+    }
+    g.nsub = best;
+    g.ncb = (sub + g.nsub - 1) / g.nsub;
+    g.nrb = (c.H + kDRows - 1) / kDRows;
+    g.Hs = g.nrb * kDRows + 2 * kDR + 1;
+    g.Ws = g.ncb * g.nsub * 8 + 2 * kDR + 1;
+    g.nchunk = (c.Cin + 15) / 16;
+    g.CoutP = (int)round_up(c.Cout, kDFB);
+    g.xd_bytes = round_up((size_t)c.N * g.nchunk * 2 * g.Hs * g.Ws * 16, 256);
+    g.wd_bytes = round_up(((size_t)g.nchunk * kDTaps + 8) * g.CoutP * 32, 256);   // + look-ahead taps of the A stream
+    return g;
+}
+
+constexpr int lds_pitch(int nsub) {       // positions; = 8 (mod 16) and >= nsub*8 + 9
+    int p = nsub * 8 + 2 * kDR + 1;
+    while (p % 16 != 8) ++p;
+    return p;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// dense kernel synthesis: WD[chunk][tap][f][sl] = sum over the units g of (c = 16*chunk + sl, f) of the bilinear weights
+// that land on tap (ty, tx).  table is indexed [Cin][G][Cout] like every gather-sum unit table (forward: w-scaled
+// factors; dx pass: the transposed table with negated offsets).  One thread per output element, coalesced writes.
+// ------------------------------------------------------------------------------------------------
+__global__ void densify_units_kernel(const UnitRef* __restrict__ table, int Cin, int G, int Cout, int CoutP, int nchunk,
+                                     __bf16* __restrict__ wd, const Guard guard) {
+    if (!guard_pass(guard)) return;
+    const long total = (long)nchunk * kDTaps * CoutP * 16;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int sl = (int)(idx & 15);
+        const int f = (int)((idx >> 4) % CoutP);
+        const int tap = (int)((idx / ((long)CoutP * 16)) % kDTaps);
+        const int chunk = (int)(idx / ((long)CoutP * 16 * kDTaps));
+        const int c = chunk * 16 + sl, ty = tap / kDK, tx = tap % kDK;
+        float v = 0.0f;
+        if (c < Cin && f < Cout) {
+            for (int g = 0; g < G; ++g) {
+                const UnitRef u = table[((long)c * G + g) * Cout + f];
+                const int ry = ty - (u.oy + kDR), rx = tx - (u.ox + kDR);     // which of the unit's 2 x 2 taps this is
+                if (ry == 0 && rx == 0) v += u.w00;
+                if (ry == 0 && rx == 1) v += u.w01;
+                if (ry == 1 && rx == 0) v += u.w10;
+                if (ry == 1 && rx == 1) v += u.w11;
+            }
+        }
+        wd[idx] = (__bf16)v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// staging: in[N,C,H,W] (bf16 or f32) -> XD (blurred with the separable Gaussian, bf16, chunked, zero border).
+// One workgroup per (image, group of 8 channels = one half of a chunk, tile of TR x TC staged positions): raw window ->
+// LDS, horizontal pass -> LDS, vertical pass -> one 16-byte unit per position.  HBM bound.
+// ------------------------------------------------------------------------------------------------
+struct DenseStageArgs {
+    const float* in;
+    const float* taps;       // 1-D factor arrays (dau_common.hpp)
+    __bf16* xd;
+    int N, C, H, W, k, mirrored, bf16;
+    int Hs, Ws, nchunk;
+    int TR, TC, ntr, ntc;    // tile of staged positions and tiles per plane
+    Guard guard;
+};
+
+// i / d for 0 <= i < 2^22 and a runtime d (the loops below index flat tiles; integer division proper costs ~40 instructions)
+__device__ __forceinline__ int fast_div(int i, int d, float inv) {
+    int q = (int)(((float)i + 0.5f) * inv);
+    const int r = i - q * d;
+    q += (r >= d) - (r < 0);
+    return q;
+}
+
+__global__ void __launch_bounds__(256) dense_stage_kernel(const DenseStageArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (!guard_pass(a.guard)) return;
+    const int k = a.k, kr = (k - 1) / 2;
+    int t = blockIdx.x;
+    const int tc = t % a.ntc; t /= a.ntc;
+    const int tr = t % a.ntr; t /= a.ntr;
+    const int grp = t % (2 * a.nchunk);        // group of 8 channels: chunk = grp / 2, half = grp & 1
+    const int n = t / (2 * a.nchunk);
+    const int r0 = tr * a.TR, c0 = tc * a.TC;  // staged origin of the tile
+    const int rows = r0 + a.TR < a.Hs ? a.TR : a.Hs - r0, cols = c0 + a.TC < a.Ws ? a.TC : a.Ws - c0;
+    const int lh = rows + k - 1, lw = cols + k - 1;
+    // four channels at a time (LDS: raw [4][lh][lw] + horizontally filtered [4][lh][cols]), two rounds per group
+    float* raw = lds;
+    float* hor = lds + 4 * lh * lw;
+    const float* gx = a.taps + (a.mirrored ? kTapGXR : kTapGX) * kTapPitch;
+    const float* gy = a.taps + (a.mirrored ? kTapGYR : kTapGY) * kTapPitch;
+    const long plane = (long)a.H * a.W;
+    const float inv_lw = 1.0f / (float)lw, inv_cols = 1.0f / (float)cols;
+    const int npos = rows * cols;
+    constexpr int kMaxPos = 5;                  // positions per thread: TR * TC <= 5 * 256
+    float res[kMaxPos][8];
+    const int plane_raw = lh * lw, plane_hor = lh * cols;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        if (round) __syncthreads();             // the vertical pass of the first round is done with `hor`
+        for (int i = threadIdx.x; i < 4 * plane_raw; i += 256) {
+            const int ch = i >= 2 * plane_raw ? (i >= 3 * plane_raw ? 3 : 2) : (i >= plane_raw ? 1 : 0);
+            const int rem = i - ch * plane_raw, y = fast_div(rem, lw, inv_lw), x = rem - y * lw;
+            const int c = grp * 8 + round * 4 + ch, iy = r0 - kDR - kr + y, ix = c0 - kDR - kr + x;
+            float v = 0.0f;
+            if (c < a.C && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = load_act(a.in, ((long)n * a.C + c) * plane + (long)iy * a.W + ix, a.bf16 != 0);
+            raw[i] = v;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 4 * plane_hor; i += 256) {
+            const int ch = i >= 2 * plane_hor ? (i >= 3 * plane_hor ? 3 : 2) : (i >= plane_hor ? 1 : 0);
+            const int rem = i - ch * plane_hor, y = fast_div(rem, cols, inv_cols), x = rem - y * cols;
+            const float* src = raw + ch * plane_raw + y * lw + x;
+            float acc = 0.0f;
+            for (int j = 0; j < k; ++j) acc = fmaf(src[j], gx[j], acc);
+            hor[i] = acc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kMaxPos; ++q) {
+            const int i = threadIdx.x + q * 256;
+            if (i < npos) {
+                const int y = fast_div(i, cols, inv_cols), x = i - y * cols;
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    float acc = 0.0f;
+                    const float* src = hor + ch * plane_hor + y * cols + x;
+                    for (int j = 0; j < k; ++j) acc = fmaf(src[j * cols], gy[j], acc);
+                    res[q][round * 4 + ch] = acc;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kMaxPos; ++q) {
+        const int i = threadIdx.x + q * 256;
+        if (i < npos) {
+            const int y = fast_div(i, cols, inv_cols), x = i - y * cols;
+            const int iy = r0 + y - kDR, ix = c0 + x - kDR;
+            const bool inside = iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;      // the blurred image is zero outside the image
+            bf16x8 o;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) o[ch] = (__bf16)(inside ? res[q][ch] : 0.0f);
+            bf16x8* dst = reinterpret_cast<bf16x8*>(a.xd) + (((long)n * 2 * a.nchunk + grp) * a.Hs + (r0 + y)) * a.Ws + (c0 + x);
+            *dst = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// main kernel
+// ------------------------------------------------------------------------------------------------
+struct DenseArgs {
+    const __bf16* xd;
+    const __bf16* wd;
+    float* out;               // [N][Cout][H][W], bf16 or f32
+    int N, Cout, CoutP, H, W, Hs, Ws, nchunk, ncb, nrb, out_bf16;
+    Guard guard;
+};
+
+template <int NSUB>
+__global__ void __launch_bounds__(256) dense_gather_kernel(const DenseArgs a) {
+    constexpr int P = lds_pitch(NSUB);                       // LDS pitch (positions)
+    constexpr int WC = NSUB * 8 + 2 * kDR + 1;               // window columns
+    constexpr int WR = kDRows + 2 * kDR + 1;                 // window rows
+    constexpr int HALF = WR * P * 16;                        // bytes of one half-plane window
+    constexpr int BUF = 2 * HALF;
+    constexpr int PIECES = 2 * WR * WC;                      // 16-byte pieces of a window
+    constexpr int PER = (PIECES + 255) / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (!guard_pass(a.guard)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fw = wave & 1, pw = wave >> 1;                 // channel half / row half of the workgroup tile
+    int t = blockIdx.x;
+    const int fb = t % (a.CoutP / kDFB); t /= (a.CoutP / kDFB);       // channel blocks fastest: they share the window
+    const int cb = t % a.ncb; t /= a.ncb;
+    const int rb = t % a.nrb;
+    const int n = t / a.nrb;
+    const int h = lane >> 5, nn = lane & 31;
+
+    // window pieces of this thread: piece p -> (half, row, col)
+    const long xd_plane = (long)a.Hs * a.Ws;                 // 16-byte units per (n, chunk, half)
+    const u32x4* xsrc = reinterpret_cast<const u32x4*>(a.xd) + ((long)n * a.nchunk * 2) * xd_plane + (long)(rb * kDRows) * a.Ws + cb * NSUB * 8;
+    int goff[PER]; unsigned loff[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        int p = threadIdx.x + i * 256;
+        if (p >= PIECES) p = PIECES - 1;                      // surplus threads repeat the last piece
+        const int ph = p / (WR * WC), rem = p - ph * (WR * WC), r = rem / WC, c = rem - r * WC;
+        goff[i] = (int)(ph * xd_plane + (long)r * a.Ws + c);
+        loff[i] = (unsigned)(ph * HALF + (r * P + c) * 16);
+    }
+    auto fetch = [&](int chunk, u32x4 (&regs)[PER]) {
+        const u32x4* src = xsrc + (long)chunk * 2 * xd_plane;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) regs[i] = src[goff[i]];
+    };
+    auto deposit = [&](int buf, const u32x4 (&regs)[PER]) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) *reinterpret_cast<u32x4*>(smem + buf * BUF + loff[i]) = regs[i];
+    };
+
+    f32x16 acc[2][NSUB];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t2][j][i] = 0.0f;
+
+    // A fragments: lane (nn, h) of tile t2 reads 16 bytes of channel fb*128 + fw*64 + t2*32 + nn
+    const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.wd) + ((long)(fb * kDFB + fw * 64 + nn)) * 2 + h;
+    const long wtap = (long)a.CoutP * 2;                      // bf16x8 units per tap
+    const unsigned lane_base = (unsigned)(h * HALF + ((4 * pw + (nn >> 3)) * P + (nn & 7)) * 16);
+
+    // Software pipeline (one wave per SIMD: nothing else hides a latency): the A fragments of tap t+4 are requested while
+    // tap t runs (five register buffers; 4 x 448 MFMA cycles cover an L2 / Infinity-Cache round trip), the B fragments of
+    // tap t+1 are read from LDS while tap t runs (two buffers).  Taps are consecutive in WD across rows, and across
+    // chunks, so the A stream is one running pointer; the last chunk's look-ahead reads the padding tap behind WD.
+    u32x4 win[PER];
+    fetch(0, win);
+    deposit(0, win);
+    bf16x8 af[5][2];
+    const bf16x8* wp = wsrc;                                  // tap 0 of chunk 0
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { af[i][0] = wp[i * wtap]; af[i][1] = wp[i * wtap + 64]; }
+    wp += 4 * wtap;                                           // next tap to request
+    __syncthreads();
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+        const int buf = chunk & 1;
+        if (chunk + 1 < a.nchunk) fetch(chunk + 1, win);      // lands under this chunk's hundred taps
+        const unsigned bbase = lane_base + buf * BUF;
+        bf16x8 bf[2][NSUB];
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) bf[0][j] = *reinterpret_cast<const bf16x8*>(smem + bbase + (8 * j) * 16);
+#pragma unroll 1
+        for (int ty = 0; ty < kDK; ++ty) {
+            const unsigned brow = bbase + ty * P * 16;
+#pragma unroll
+            for (int tx = 0; tx < kDK; ++tx) {
+                constexpr int kAhead = 4;
+                const int cur = tx % 5, nxt = (tx + kAhead) % 5, pb = tx & 1;
+                af[nxt][0] = wp[0]; af[nxt][1] = wp[64];
+                wp += wtap;
+                // B fragments of the next tap of this chunk (the last tap of a chunk has no successor in this window)
+                if (tx + 1 < kDK) {
+#pragma unroll
+                    for (int j = 0; j < NSUB; ++j) bf[pb ^ 1][j] = *reinterpret_cast<const bf16x8*>(smem + brow + (tx + 1 + 8 * j) * 16);
+                } else if (ty + 1 < kDK) {
+#pragma unroll
+                    for (int j = 0; j < NSUB; ++j) bf[pb ^ 1][j] = *reinterpret_cast<const bf16x8*>(smem + brow + P * 16 + (8 * j) * 16);
+                }
+#pragma unroll
+                for (int j = 0; j < NSUB; ++j) {
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][0], bf[pb][j], acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][1], bf[pb][j], acc[1][j], 0, 0, 0);
+                }
+            }
+        }
+        if (chunk + 1 < a.nchunk) {
+            deposit(buf ^ 1, win);                             // nobody reads that buffer during this chunk
+            __syncthreads();
+        }
+    }
+
+    // epilogue: C/D layout of the 32x32 tile: column (pixel) = lane & 31, row (channel) = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
+    const int y = rb * kDRows + 4 * pw + (nn >> 3);
+    const long plane = (long)a.H * a.W;
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j) {
+            const int x = cb * NSUB * 8 + 8 * j + (nn & 7);
+            if (y < a.H && x < a.W) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int f = fb * kDFB + fw * 64 + t2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (f < a.Cout) store_act(a.out, ((long)n * a.Cout + f) * plane + (long)y * a.W + x, acc[t2][j][i], a.out_bf16 != 0, false);
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+template <int NSUB>
+void launch_dense(hipStream_t st, const DenseArgs* a, int grid) {
+    constexpr size_t lds = 2 * 2 * (size_t)(kDRows + 2 * kDR + 1) * lds_pitch(NSUB) * 16;
+    auto kern = dense_gather_kernel<NSUB>;
+    if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return; }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, *a);
+}
+
+void dispatch_dense(int nsub, hipStream_t st, const DenseArgs* a, int grid) {
+    switch (nsub) {
+        case 2: launch_dense<2>(st, a, grid); break;
+        case 4: launch_dense<4>(st, a, grid); break;
+        case 7: launch_dense<7>(st, a, grid); break;
+        default: launch_dense<8>(st, a, grid); break;
+    }
+}
+
+void stage_tile(const DenseConfig& c, const DenseGeom& g, int* TR, int* TC, size_t* lds) {
+    // tile of at most 5 * 256 staged positions (the kernel keeps its results in registers) whose raw window of four
+    // channels and horizontally filtered rows fit ~50 KiB of LDS (three workgroups per CU)
+    int tc = g.Ws < 80 ? g.Ws : 64, tr = g.Hs < 24 ? g.Hs : 16;
+    auto bytes = [&](int r, int cc) { return (size_t)4 * (r + c.blur_k - 1) * ((cc + c.blur_k - 1) + cc) * 4; };
+    while ((bytes(tr, tc) > 52 * 1024 || tr * tc > 5 * 256) && tr > 4) tr -= 4;
+    while ((bytes(tr, tc) > 52 * 1024 || tr * tc > 5 * 256) && tc > 16) tc -= 16;
+    *TR = tr; *TC = tc; *lds = bytes(tr, tc);
+}
+
+}  // namespace
+
+bool dense_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, bool bf16, DenseConfig* cfg) {
+    if (R != kDR || !bf16) return false;          // the 10 x 10 dense kernel covers offsets within +-4; bf16 layers only
+    DenseConfig c{};
+    c.N = N; c.Cin = Cin; c.Cout = Cout; c.G = G; c.H = H; c.W = W; c.R = R; c.blur_k = blur_k; c.bf16 = 1;
+    const DenseGeom g = dense_geometry(c);
+    c.nsub = g.nsub;
+    int tr, tc; size_t lds;
+    stage_tile(c, g, &tr, &tc, &lds);
+    if (lds > 150 * 1024) return false;
+    // 32-bit unit offsets inside one image's staged planes
+    if ((size_t)g.nchunk * 2 * g.Hs * g.Ws > (size_t)1 << 30) return false;
+    *cfg = c;
+    return true;
+}
+
+size_t dense_gather_workspace_bytes(const DenseConfig& c) {
+    const DenseGeom g = dense_geometry(c);
+    return g.xd_bytes + g.wd_bytes;
+}
+
+void dense_gather_init(const DenseConfig& c) {
+    dispatch_dense(c.nsub, nullptr, nullptr, 0);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_stage_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+void dense_gather_prepare(hipStream_t st, const DenseConfig& c, const float* in, const float* filters, bool mirrored,
+                          const UnitRef* table, void* workspace, const Guard& guard) {
+    const DenseGeom g = dense_geometry(c);
+    char* ws = static_cast<char*>(workspace);
+    __bf16* xd = reinterpret_cast<__bf16*>(ws);
+    __bf16* wd = reinterpret_cast<__bf16*>(ws + g.xd_bytes);
+    {
+        const long total = (long)g.nchunk * kDTaps * g.CoutP * 16;
+        const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+        hipLaunchKernelGGL(densify_units_kernel, dim3(grid), dim3(256), 0, st, table, c.Cin, c.G, c.Cout, g.CoutP, g.nchunk, wd, guard);
+    }
+    {
+        DenseStageArgs s{};
+        s.in = in; s.taps = filters + kTaps1dOffset; s.xd = xd;
+        s.N = c.N; s.C = c.Cin; s.H = c.H; s.W = c.W; s.k = c.blur_k; s.mirrored = mirrored ? 1 : 0; s.bf16 = c.bf16;
+        s.Hs = g.Hs; s.Ws = g.Ws; s.nchunk = g.nchunk; s.guard = guard;
+        size_t lds;
+        stage_tile(c, g, &s.TR, &s.TC, &lds);
+        s.ntr = (g.Hs + s.TR - 1) / s.TR; s.ntc = (g.Ws + s.TC - 1) / s.TC;
+        hipLaunchKernelGGL(dense_stage_kernel, dim3(c.N * 2 * g.nchunk * s.ntr * s.ntc), dim3(256), lds, st, s);
+    }
+}
+
+void dense_gather_run(hipStream_t st, const DenseConfig& c, float* out, void* workspace, const Guard& guard) {
+    const DenseGeom g = dense_geometry(c);
+    char* ws = static_cast<char*>(workspace);
+    const __bf16* xd = reinterpret_cast<const __bf16*>(ws);
+    const __bf16* wd = reinterpret_cast<const __bf16*>(ws + g.xd_bytes);
+    DenseArgs a{};
+    a.xd = xd; a.wd = wd; a.out = out;
+    a.N = c.N; a.Cout = c.Cout; a.CoutP = g.CoutP; a.H = c.H; a.W = c.W; a.Hs = g.Hs; a.Ws = g.Ws; a.nchunk = g.nchunk;
+    a.ncb = g.ncb; a.nrb = g.nrb; a.out_bf16 = c.bf16; a.guard = guard;
+    const int grid = c.N * g.nrb * g.ncb * (g.CoutP / kDFB);
+    dispatch_dense(c.nsub, st, &a, grid);
+}
+
+}  // namespace dau

@@ -21,6 +21,7 @@ FLAG_SINGLE_DIM_KERNEL = 1 << 2
 FLAG_FORBID_POSITIVE_DIM1 = 1 << 3
 FLAG_IO_BF16 = 1 << 4   # x, y, dy, dx are torch.bfloat16; parameters and their gradients stay float32
 FLAG_STATIC_BUCKET = 1 << 5   # always the kernels of the bucket max_kernel_size allows (no per-call selection)
+FLAG_DENSE_BF16 = 1 << 6      # with FLAG_IO_BF16: gather-sum passes of calls with |mu| <= 4 as a densified bf16 MFMA GEMM
 
 ALGO_AUTO, ALGO_DIRECT, ALGO_TILED = 0, 1, 2
 PASS_FORWARD, PASS_BACKWARD = 1, 2
@@ -57,7 +58,7 @@ class _Desc(ctypes.Structure):
 class _Info(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ("offset_bucket", "blur_support", "algo_forward", "algo_backward", "drop_last_col", "drop_last_row",
-                 "gather_patch", "gather_stack", "dot_windows", "gather_windows", "bucket_sets")]
+                 "gather_patch", "gather_stack", "dot_windows", "gather_windows", "bucket_sets", "gather_dense_bf16")]
 
 
 def _load():

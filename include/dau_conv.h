@@ -95,6 +95,11 @@ enum {
                                                creation fails where only the direct ones apply.        */
     DAU_FLAG_STATIC_BUCKET = 1 << 5,        /* always run the kernels of the bucket max_kernel_size allows (no
                                                per-call selection from the actual offsets)             */
+    DAU_FLAG_DENSE_BF16 = 1 << 6,           /* with DAU_FLAG_IO_BF16: calls whose offsets lie within +-4 run their
+                                               two gather-sum passes (y, dx) as a DENSIFIED implicit GEMM on the
+                                               bf16 matrix cores (units scattered into a 10x10 kernel per channel
+                                               pair; taps and blurred activations rounded to bf16, fp32 sums).
+                                               Parameter gradients keep the exact fp32 path.                  */
     DAU_FLAG_DEFAULT = DAU_FLAG_USE_INTERPOLATION
 };
 
@@ -150,6 +155,7 @@ typedef struct dau_conv_plan_info {
     int32_t dot_windows;       /* tiled gather-dot: offset windows (1 for kernels <= 17)          */
     int32_t gather_windows;    /* tiled gather-sum: offset-window passes (1 for kernels <= 33)    */
     int32_t bucket_sets;       /* kernel sets a call can choose from (1: static bucket only)      */
+    int32_t gather_dense_bf16; /* 1: the bucket-4 gather-sum passes use the densified bf16 GEMM   */
 } dau_conv_plan_info;
 
 DAU_API int dau_conv_abi_version(void);

@@ -1,0 +1,112 @@
+"""GPU: the densified bf16 gather-sum (DAU_FLAG_DENSE_BF16 + DAU_FLAG_IO_BF16, k_dense_bf16.hip): for calls whose offsets lie
+within +-4 the two gather-sum passes (y and dx) run as an implicit GEMM on the bf16 matrix cores over a dense 10 x 10
+kernel per channel pair.  Bar (SURVEY.md 8d, bf16 configuration): 2e-2 relative + 4e-3 of the max-norm against the fp32
+oracle fed the bf16-rounded inputs; the parameter gradients do not use the dense form and keep the fp32 bar."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dau_oracle as orc
+from util import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed, N, S, F, G, H, W, m):
+    rs = np.random.RandomState(seed)
+    xb = torch.from_numpy(rs.rand(N, S, H, W).astype(np.float32)).to(torch.bfloat16)
+    dyb = torch.from_numpy(rs.randn(N, F, H, W).astype(np.float32)).to(torch.bfloat16)
+    w = (rs.randn(1, S, G, F) * 0.1).astype(np.float32)
+    mu1 = rs.uniform(-m, m, (1, S, G, F)).astype(np.float32)
+    mu2 = rs.uniform(-m, m, (1, S, G, F)).astype(np.float32)
+    return xb, dyb, w, mu1, mu2
+
+
+def _run(plan, xb, dyb, w, mu1, mu2, calls=1):
+    dev = lambda a: torch.from_numpy(a).cuda()
+    S, G, F = w.shape[1:]
+    sigma = torch.full((1, S, G, F), 0.5, device="cuda")
+    for _ in range(calls):
+        y = plan.forward(xb.cuda(), dev(w), dev(mu1), dev(mu2), sigma)
+        plan.check_status()
+        g = plan.backward(xb.cuda(), dyb.cuda(), dev(w), dev(mu1), dev(mu2), sigma)
+        plan.check_status()
+    torch.cuda.synchronize()
+    return y, g
+
+
+def _check(y, g, xb, dyb, w, mu1, mu2, name):
+    x32, dy32 = xb.float().numpy(), dyb.float().numpy()
+    want_y = orc.forward(x32, w, mu1, mu2, 0.5)
+    want = orc.backward(x32, dy32, w, mu1, mu2, 0.5)
+    assert y.dtype == torch.bfloat16 and g[0].dtype == torch.bfloat16
+    assert_parity(y.float().cpu().numpy(), want_y, name + "/y", rel=2e-2, floor=4e-3)
+    assert_parity(g[0].float().cpu().numpy(), want["dx"], name + "/dx", rel=2e-2, floor=4e-3)
+    for t, key in zip(g[1:], ("dw", "dmu1", "dmu2", "dsigma")):
+        assert_parity(t.cpu().numpy(), want[key], name + "/" + key)
+
+
+@pytest.mark.parametrize("shape", [
+    dict(N=2, S=16, F=128, G=4, H=56, W=56),      # one column block of 7 subtiles, whole chunks and channel blocks
+    dict(N=3, S=20, F=40, G=3, H=30, W=45),       # ragged everything: channels, rows, columns, odd batch
+    dict(N=2, S=7, F=5, G=2, H=9, W=6),           # tiny
+    dict(N=2, S=33, F=130, G=6, H=28, W=28),      # two channel blocks, the second almost empty
+    dict(N=1, S=16, F=16, G=2, H=20, W=130),      # three column blocks
+    dict(N=2, S=32, F=64, G=1, H=17, W=64),       # eight subtiles per block
+    dict(N=4, S=24, F=32, G=5, H=14, W=14),       # two subtiles
+])
+def test_dense_bf16_gather_against_oracle(shape):
+    from dau_conv import _capi
+    N, S, F, G, H, W = (shape[q] for q in ("N", "S", "F", "G", "H", "W"))
+    xb, dyb, w, mu1, mu2 = _case(41, N, S, F, G, H, W, 3.99)
+    mu1.flat[0] = 3.99; mu2.flat[0] = -3.99; mu1.flat[1] = -4.0; mu2.flat[1] = 4.0       # the corners of the 10 x 10 kernel
+    flags = _capi.FLAG_USE_INTERPOLATION | _capi.FLAG_IO_BF16 | _capi.FLAG_DENSE_BF16
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=flags)
+    assert plan.info["gather_dense_bf16"] == 1
+    y, g = _run(plan, xb, dyb, w, mu1, mu2)
+    _check(y, g, xb, dyb, w, mu1, mu2, "dense")
+
+
+def test_dense_bf16_under_a_larger_kernel_follows_the_offsets():
+    """max_kernel_size 17 with the dense flag: calls with |mu| <= 4 take the dense GEMM (after the first call has left its
+    hint), calls with larger offsets the exact gather of bucket 8; both match the oracle."""
+    from dau_conv import _capi
+    N, S, F, G, H, W = 3, 18, 36, 4, 33, 40
+    flags = _capi.FLAG_USE_INTERPOLATION | _capi.FLAG_IO_BF16 | _capi.FLAG_DENSE_BF16
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=17, sigma_hint=0.5, flags=flags)
+    assert plan.info["gather_dense_bf16"] == 1 and plan.info["bucket_sets"] == 2
+    small = _case(42, N, S, F, G, H, W, 3.5)
+    y, g = _run(plan, *small, calls=2)
+    _check(y, g, *small, "small offsets (dense)")
+    big = _case(43, N, S, F, G, H, W, 7.5)
+    y, g = _run(plan, *big)                        # stale hint (3.5): the guard sends the call to the bucket-8 gather
+    _check(y, g, *big, "large offsets (gather)")
+    y, g = _run(plan, *big)
+    _check(y, g, *big, "large offsets again")
+
+
+def test_dense_flag_needs_bf16_io():
+    from dau_conv import _capi
+    with pytest.raises(_capi.InvalidArgumentError):
+        _capi.Plan(2, 4, 8, 2, 16, 16, flags=_capi.FLAG_USE_INTERPOLATION | _capi.FLAG_DENSE_BF16)
+
+
+def test_dense_bf16_through_the_layer():
+    import dau_conv
+    torch.manual_seed(1)
+    kw = dict(filters=24, dau_units=(2, 2), max_kernel_size=9, in_channels=10, use_bias=False)
+    exact = dau_conv.DAUConv2d(**kw).cuda()
+    dense = dau_conv.DAUConv2d(dense_bf16=True, **kw).cuda()
+    dense.load_state_dict(exact.state_dict())
+    x = torch.rand(3, 10, 21, 37, device="cuda").to(torch.bfloat16)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = exact(xa), dense(xb)
+    assert yb.dtype == torch.bfloat16
+    dy = torch.randn_like(ya)
+    ya.backward(dy); yb.backward(dy)
+    scale = float(ya.float().abs().max())
+    assert float((ya.float() - yb.float()).abs().max()) <= 2e-2 * scale
+    gs = float(xa.grad.float().abs().max())
+    assert float((xa.grad.float() - xb.grad.float()).abs().max()) <= 2e-2 * gs
+    # the parameter gradients do not go through the dense form: identical
+    assert torch.equal(exact.weights.grad, dense.weights.grad) and torch.equal(exact.mu1.grad, dense.mu1.grad)
