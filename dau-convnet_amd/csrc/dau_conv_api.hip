@@ -77,8 +77,8 @@ struct BucketSet {
     bool dense_ok = false;
     DenseConfig dense_fwd, dense_dx;
 };
-constexpr int kBuckets[] = {4, 8, 16, 20, 24, 32};
-constexpr int kNumBuckets = 6;
+constexpr int kBuckets[] = {4, 8, 16, 18, 20, 24, 32};
+constexpr int kNumBuckets = 7;
 
 struct dau_conv_plan {
     dau_conv_desc d;
@@ -285,6 +285,7 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
     if (half <= 4) bucket = 4;
     else if (half <= 8) bucket = 8;
     else if (half <= 16) bucket = 16;
+    else if (half <= 18) bucket = 18;
     else if (half <= 20) bucket = 20;
     else if (half <= 24) bucket = 24;
     else if (half <= 32) bucket = 32;

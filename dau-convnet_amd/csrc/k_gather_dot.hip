@@ -80,14 +80,18 @@ struct DotGeometry {
 // as1 / one_tile: tuning choices fixed at plan creation (TiledDotConfig), so that every later call sees the same layout
 DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one_tile = false, int rounds = 0) {
     DotGeometry g{};
-    g.Rt = R < 8 ? R : 8;
+    // Bucket 18 (offsets within +-18: BASELINE config 4 has +-17): 2 x 2 windows of radius 9 over regions of 4 x 8
+    // positions (a 23 x 27 tile fills the LDS like the 25 x 25 one) instead of 3 x 3 windows of radius 8 over 8 x 8
+    // regions -- fewer, fuller windows (about 2.25 units per (s, f, window) instead of 1)
+    const bool wide = R == 18;
+    g.Rt = wide ? 9 : (R < 8 ? R : 8);
     g.nsub1 = (R + g.Rt - 1) / g.Rt;
     g.Rp = g.nsub1 * g.Rt;
     R = g.Rp;
     const bool binned = g.nsub1 > 1;
     g.epitch = kRW + 2 * g.Rt + 1;
     // rows per region: 7 when that pads the height less (7, 14, 21, 27, 28, ...)
-    g.RH = ((sh.H + 6) / 7) * 7 < ((sh.H + 7) / 8) * 8 ? 7 : 8;
+    g.RH = wide ? 4 : (((sh.H + 6) / 7) * 7 < ((sh.H + 7) / 8) * 8 ? 7 : 8);
     g.erows = g.RH + 2 * g.Rt + 1;
     g.rx = (sh.W + kRW - 1) / kRW;
     g.ry = (sh.H + g.RH - 1) / g.RH;
@@ -842,6 +846,7 @@ void launch_dot(hipStream_t st, const DotArgs* a, int grid, size_t lds) {
 void dispatch_dot(bool binned, int RH, int GP, int AS, hipStream_t st, const DotArgs* a, int grid, size_t lds) {
     if (binned) {
         if (RH == 8) launch_dot<1, 4, 8, true>(st, a, grid, lds);
+        else if (RH == 4) launch_dot<1, 4, 4, true>(st, a, grid, lds);
         else launch_dot<1, 4, 7, true>(st, a, grid, lds);
     } else if (RH == 8) {
         if (GP == 1) launch_dot<1, 4, 8>(st, a, grid, lds);

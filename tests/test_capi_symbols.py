@@ -39,7 +39,7 @@ def test_plan_validation_without_device():
     p = _capi.Plan(2, 3, 4, 2, 8, 9, max_kernel_size=9, sigma_hint=0.5)
     assert p.info["offset_bucket"] == 4 and p.info["blur_support"] == 7
     assert p.workspace_bytes(_capi.PASS_FORWARD) > 0 and p.workspace_bytes(_capi.PASS_BACKWARD) > p.workspace_bytes(_capi.PASS_FORWARD)
-    for k, bucket in ((17, 8), (33, 16), (49, 24), (65, 32), (11, 8), (35, 24)):
+    for k, bucket in ((17, 8), (33, 16), (37, 18), (41, 20), (49, 24), (65, 32), (11, 8), (35, 18)):
         assert _capi.Plan(1, 1, 1, 2, 8, 8, max_kernel_size=k).info["offset_bucket"] == bucket
     with pytest.raises(_capi.InvalidArgumentError):
         _capi.Plan(1, 1, 1, 2, 8, 8, max_kernel_size=67)          # offsets beyond 32 px (dau_conv_op.cpp:245-248)
@@ -50,7 +50,7 @@ def test_plan_validation_without_device():
     with pytest.raises(_capi.InvalidArgumentError):
         _capi.Plan(1, 1, 1, 2, 8, 8, number_units_ignore=2)
     # kernel sets a call can choose from: every bucket up to the static one, unless pinned
-    assert _capi.Plan(2, 4, 8, 2, 32, 32, max_kernel_size=65).info["bucket_sets"] == 5
+    assert _capi.Plan(2, 4, 8, 2, 32, 32, max_kernel_size=65).info["bucket_sets"] == 7
     assert _capi.Plan(2, 4, 8, 2, 32, 32, max_kernel_size=9).info["bucket_sets"] == 1
     assert _capi.Plan(2, 4, 8, 2, 32, 32, max_kernel_size=65,
                       flags=_capi.FLAG_USE_INTERPOLATION | _capi.FLAG_STATIC_BUCKET).info["bucket_sets"] == 1

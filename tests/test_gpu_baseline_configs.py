@@ -102,8 +102,8 @@ def test_c2_six_units_bf16_activations():
 @pytest.mark.parametrize("static_bucket", [False, True])
 def test_c4_seg_scale_large_offsets(static_bucket):
     """BASELINE config 4's workload: 512x512, nine live units of ten, kernel 65, offsets within +-17.  With per-call
-    selection the second call runs the bucket-20 kernels (one gather pass over edge-free 31 pixel patches, 9 binned
-    gather-dot windows); with DAU_FLAG_STATIC_BUCKET the bucket-32 ones (4 binned gather windows of radius 16, 16
+    selection the second call runs the bucket-18 kernels (one gather pass over edge-free 31 pixel patches, 2 x 2 binned
+    gather-dot windows of radius 9 over 4 x 8 regions); with DAU_FLAG_STATIC_BUCKET the bucket-32 ones (4 binned gather windows of radius 16, 16
     gather-dot windows).  Both must match the oracle."""
     from dau_conv import _capi
     N, S, F, G, H, W, k = 2, 4, 32, 10, 512, 512, 65
@@ -111,7 +111,7 @@ def test_c4_seg_scale_large_offsets(static_bucket):
     flags = _capi.FLAG_USE_INTERPOLATION | (_capi.FLAG_STATIC_BUCKET if static_bucket else 0)
     plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, number_units_ignore=1, sigma_hint=0.5, flags=flags)
     assert plan.info["algo_forward"] == _capi.ALGO_TILED and plan.info["algo_backward"] == _capi.ALGO_TILED
-    assert plan.info["offset_bucket"] == 32 and plan.info["bucket_sets"] == (1 if static_bucket else 6)
+    assert plan.info["offset_bucket"] == 32 and plan.info["bucket_sets"] == (1 if static_bucket else 7)
     got = _run(plan, x, dy, w, mu1, mu2, calls=2)        # the second call has the first one's max|mu| as its hint
     _check_all(got, x, dy, w, mu1, mu2, "C4", ignore=1)
     assert float(np.abs(got["dw"][:, :, G - 1]).max()) == 0.0
@@ -127,6 +127,10 @@ def test_c4_seg_scale_large_offsets(static_bucket):
     dict(N=2, S=4, F=32, G=6, H=64, W=64, k=65, m=12.0),
     dict(N=2, S=4, F=32, G=5, H=64, W=64, k=65, m=20.0),
     dict(N=2, S=3, F=16, G=2, H=30, W=70, k=49, m=23.5),
+    # bucket 18 (radius-9 windows over 4 x 8 regions) and bucket 20, declared and hinted
+    dict(N=2, S=5, F=40, G=7, H=37, W=50, k=37, m=17.99),
+    dict(N=3, S=4, F=32, G=9, H=30, W=30, k=65, m=17.0),
+    dict(N=2, S=4, F=20, G=3, H=26, W=41, k=41, m=19.5),
 ])
 def test_big_kernel_small_offsets_dynamic_bucket(shape):
     """Three calls of one plan: without a hint (static bucket), with the hint of the same offsets (small bucket), and
