@@ -46,6 +46,7 @@ struct DenseConfig {
     int R, blur_k;
     int bf16;         // activations in and out are bfloat16 (required)
     int nsub;         // 8-pixel subtiles per column block = kernel instantiation
+    int ftiles;       // 32-channel accumulator tiles per wave (2: four waves per workgroup, 1: eight)
 };
 bool dense_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, bool bf16, DenseConfig* cfg);
 size_t dense_gather_workspace_bytes(const DenseConfig& cfg);

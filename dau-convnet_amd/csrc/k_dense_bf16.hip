@@ -19,8 +19,9 @@
 //       16-byte unit per position and half = the B fragment of one lane), staged position (r, c) = image (r-4, c-4),
 //       zero outside the image; Hs, Ws cover whole row / column blocks plus the 9-position tap border.
 //   WD[chunk][tap][CoutP][16]      bf16: the dense kernel, 32 bytes per output channel (A fragments of the two lane halves).
-// Workgroup = 4 waves = 2 (64 output channels each) x 2 (4 rows each): 128 output channels x 8 rows x NSUB*8 columns;
-// a wave owns 2 x NSUB accumulator tiles of 32 channels x (4 rows x 8 columns).  Per chunk the 17 x (NSUB*8+9) window of
+// Workgroup = 128 output channels x 8 rows x NSUB*8 columns, as 8 waves = 4 (32 channels each) x 2 (4 rows each), two per
+// SIMD (or 4 waves with two channel tiles each, FT = 2); a wave owns FT x NSUB accumulator tiles of 32 channels x (4 rows x
+// 8 columns).  Per chunk the 17 x (NSUB*8+9) window of
 // both halves sits in LDS (pitch = 8 mod 16 positions: the four rows of a B fragment fall on different banks); per tap a
 // wave loads two A fragments from global memory (L1/L2 resident: 8 KB per tap and chunk for 256 channels) and NSUB B
 // fragments with ds_read_b128 at the tap's displacement, and issues 2*NSUB MFMAs.
@@ -221,19 +222,23 @@ struct DenseArgs {
     Guard guard;
 };
 
-template <int NSUB>
-__global__ void __launch_bounds__(256) dense_gather_kernel(const DenseArgs a) {
+// FT: 32-channel accumulator tiles per wave: 2 -> 4 waves per workgroup (one per SIMD), 1 -> 8 waves (two per SIMD, half
+// the accumulators each, every B fragment read by twice as many waves)
+template <int NSUB, int FT>
+__global__ void __launch_bounds__(FT == 2 ? 256 : 512) dense_gather_kernel(const DenseArgs a) {
+    constexpr int kThreads = FT == 2 ? 256 : 512;
     constexpr int P = lds_pitch(NSUB);                       // LDS pitch (positions)
     constexpr int WC = NSUB * 8 + 2 * kDR + 1;               // window columns
     constexpr int WR = kDRows + 2 * kDR + 1;                 // window rows
     constexpr int HALF = WR * P * 16;                        // bytes of one half-plane window
     constexpr int BUF = 2 * HALF;
     constexpr int PIECES = 2 * WR * WC;                      // 16-byte pieces of a window
-    constexpr int PER = (PIECES + 255) / 256;
+    constexpr int PER = (PIECES + kThreads - 1) / kThreads;
+    constexpr int FW = 4 / FT;                               // waves along the 128 output channels
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (!guard_pass(a.guard)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int fw = wave & 1, pw = wave >> 1;                 // channel half / row half of the workgroup tile
+    const int fw = wave % FW, pw = wave / FW;                // channel part / row half of the workgroup tile
     int t = blockIdx.x;
     const int fb = t % (a.CoutP / kDFB); t /= (a.CoutP / kDFB);       // channel blocks fastest: they share the window
     const int cb = t % a.ncb; t /= a.ncb;
@@ -247,7 +252,7 @@ __global__ void __launch_bounds__(256) dense_gather_kernel(const DenseArgs a) {
     int goff[PER]; unsigned loff[PER];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-        int p = threadIdx.x + i * 256;
+        int p = threadIdx.x + i * kThreads;
         if (p >= PIECES) p = PIECES - 1;                      // surplus threads repeat the last piece
         const int ph = p / (WR * WC), rem = p - ph * (WR * WC), r = rem / WC, c = rem - r * WC;
         goff[i] = (int)(ph * xd_plane + (long)r * a.Ws + c);
@@ -263,16 +268,16 @@ __global__ void __launch_bounds__(256) dense_gather_kernel(const DenseArgs a) {
         for (int i = 0; i < PER; ++i) *reinterpret_cast<u32x4*>(smem + buf * BUF + loff[i]) = regs[i];
     };
 
-    f32x16 acc[2][NSUB];
+    f32x16 acc[FT][NSUB];
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
+    for (int t2 = 0; t2 < FT; ++t2)
 #pragma unroll
         for (int j = 0; j < NSUB; ++j)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[t2][j][i] = 0.0f;
 
-    // A fragments: lane (nn, h) of tile t2 reads 16 bytes of channel fb*128 + fw*64 + t2*32 + nn
-    const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.wd) + ((long)(fb * kDFB + fw * 64 + nn)) * 2 + h;
+    // A fragments: lane (nn, h) of tile t2 reads 16 bytes of channel fb*128 + fw*32*FT + t2*32 + nn
+    const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.wd) + ((long)(fb * kDFB + fw * 32 * FT + nn)) * 2 + h;
     const long wtap = (long)a.CoutP * 2;                      // bf16x8 units per tap
     const unsigned lane_base = (unsigned)(h * HALF + ((4 * pw + (nn >> 3)) * P + (nn & 7)) * 16);
 
@@ -283,10 +288,12 @@ __global__ void __launch_bounds__(256) dense_gather_kernel(const DenseArgs a) {
     u32x4 win[PER];
     fetch(0, win);
     deposit(0, win);
-    bf16x8 af[5][2];
+    bf16x8 af[5][FT];
     const bf16x8* wp = wsrc;                                  // tap 0 of chunk 0
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { af[i][0] = wp[i * wtap]; af[i][1] = wp[i * wtap + 64]; }
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t2 = 0; t2 < FT; ++t2) af[i][t2] = wp[i * wtap + 64 * t2];
     wp += 4 * wtap;                                           // next tap to request
     __syncthreads();
     for (int chunk = 0; chunk < a.nchunk; ++chunk) {
@@ -303,7 +310,8 @@ __global__ void __launch_bounds__(256) dense_gather_kernel(const DenseArgs a) {
             for (int tx = 0; tx < kDK; ++tx) {
                 constexpr int kAhead = 4;
                 const int cur = tx % 5, nxt = (tx + kAhead) % 5, pb = tx & 1;
-                af[nxt][0] = wp[0]; af[nxt][1] = wp[64];
+#pragma unroll
+                for (int t2 = 0; t2 < FT; ++t2) af[nxt][t2] = wp[64 * t2];
                 wp += wtap;
                 // B fragments of the next tap of this chunk (the last tap of a chunk has no successor in this window)
                 if (tx + 1 < kDK) {
@@ -314,10 +322,10 @@ __global__ void __launch_bounds__(256) dense_gather_kernel(const DenseArgs a) {
                     for (int j = 0; j < NSUB; ++j) bf[pb ^ 1][j] = *reinterpret_cast<const bf16x8*>(smem + brow + P * 16 + (8 * j) * 16);
                 }
 #pragma unroll
-                for (int j = 0; j < NSUB; ++j) {
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][0], bf[pb][j], acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][1], bf[pb][j], acc[1][j], 0, 0, 0);
-                }
+                for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+                    for (int t2 = 0; t2 < FT; ++t2)
+                        acc[t2][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][t2], bf[pb][j], acc[t2][j], 0, 0, 0);
             }
         }
         if (chunk + 1 < a.nchunk) {
@@ -330,14 +338,14 @@ __global__ void __launch_bounds__(256) dense_gather_kernel(const DenseArgs a) {
     const int y = rb * kDRows + 4 * pw + (nn >> 3);
     const long plane = (long)a.H * a.W;
 #pragma unroll
-    for (int t2 = 0; t2 < 2; ++t2)
+    for (int t2 = 0; t2 < FT; ++t2)
 #pragma unroll
         for (int j = 0; j < NSUB; ++j) {
             const int x = cb * NSUB * 8 + 8 * j + (nn & 7);
             if (y < a.H && x < a.W) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int f = fb * kDFB + fw * 64 + t2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    const int f = fb * kDFB + fw * 32 * FT + t2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
                     if (f < a.Cout) store_act(a.out, ((long)n * a.Cout + f) * plane + (long)y * a.W + x, acc[t2][j][i], a.out_bf16 != 0, false);
                 }
             }
@@ -349,20 +357,29 @@ __global__ void __launch_bounds__(256) dense_gather_kernel(const DenseArgs a) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-template <int NSUB>
+template <int NSUB, int FT>
 void launch_dense(hipStream_t st, const DenseArgs* a, int grid) {
     constexpr size_t lds = 2 * 2 * (size_t)(kDRows + 2 * kDR + 1) * lds_pitch(NSUB) * 16;
-    auto kern = dense_gather_kernel<NSUB>;
+    auto kern = dense_gather_kernel<NSUB, FT>;
     if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return; }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, *a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(FT == 2 ? 256 : 512), lds, st, *a);
 }
 
-void dispatch_dense(int nsub, hipStream_t st, const DenseArgs* a, int grid) {
+void dispatch_dense(int nsub, int ft, hipStream_t st, const DenseArgs* a, int grid) {
+    if (ft == 1) {
+        switch (nsub) {
+            case 2: launch_dense<2, 1>(st, a, grid); break;
+            case 4: launch_dense<4, 1>(st, a, grid); break;
+            case 7: launch_dense<7, 1>(st, a, grid); break;
+            default: launch_dense<8, 1>(st, a, grid); break;
+        }
+        return;
+    }
     switch (nsub) {
-        case 2: launch_dense<2>(st, a, grid); break;
-        case 4: launch_dense<4>(st, a, grid); break;
-        case 7: launch_dense<7>(st, a, grid); break;
-        default: launch_dense<8>(st, a, grid); break;
+        case 2: launch_dense<2, 2>(st, a, grid); break;
+        case 4: launch_dense<4, 2>(st, a, grid); break;
+        case 7: launch_dense<7, 2>(st, a, grid); break;
+        default: launch_dense<8, 2>(st, a, grid); break;
     }
 }
 
@@ -388,6 +405,10 @@ bool dense_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R
     c.N = N; c.Cin = Cin; c.Cout = Cout; c.G = G; c.H = H; c.W = W; c.R = R; c.blur_k = blur_k; c.bf16 = 1;
     const DenseGeom g = dense_geometry(c);
     c.nsub = g.nsub;
+    // accumulator tiles per wave: 1 = eight waves per workgroup, two per SIMD (default: 3.71 ms against 4.24 ms with four
+    // waves at BASELINE config 2, same box); DAU_DENSE_FT=2 at plan creation selects the four-wave form
+    c.ftiles = getenv("DAU_DENSE_FT") ? atoi(getenv("DAU_DENSE_FT")) : 1;
+    if (c.ftiles != 2) c.ftiles = 1;
     int tr, tc; size_t lds;
     stage_tile(c, g, &tr, &tc, &lds);
     if (lds > 150 * 1024) return false;
@@ -403,7 +424,7 @@ size_t dense_gather_workspace_bytes(const DenseConfig& c) {
 }
 
 void dense_gather_init(const DenseConfig& c) {
-    dispatch_dense(c.nsub, nullptr, nullptr, 0);
+    dispatch_dense(c.nsub, c.ftiles, nullptr, nullptr, 0);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_stage_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -440,7 +461,7 @@ void dense_gather_run(hipStream_t st, const DenseConfig& c, float* out, void* wo
     a.N = c.N; a.Cout = c.Cout; a.CoutP = g.CoutP; a.H = c.H; a.W = c.W; a.Hs = g.Hs; a.Ws = g.Ws; a.nchunk = g.nchunk;
     a.ncb = g.ncb; a.nrb = g.nrb; a.out_bf16 = c.bf16; a.guard = guard;
     const int grid = c.N * g.nrb * g.ncb * (g.CoutP / kDFB);
-    dispatch_dense(c.nsub, st, &a, grid);
+    dispatch_dense(c.nsub, c.ftiles, st, &a, grid);
 }
 
 }  // namespace dau

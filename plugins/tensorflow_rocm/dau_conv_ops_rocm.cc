@@ -11,6 +11,8 @@
 //         -L../../dau-convnet_amd/dau_conv -ldau_conv_hip -o dau_conv_op.so
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
 #include <string>
 
 #include "dau_conv.h"
@@ -132,6 +134,27 @@ hipStream_t StreamOf(tf::OpKernelContext* ctx) {
     return *reinterpret_cast<hipStream_t*>(ctx->op_device_context()->stream()->platform_specific_handle().stream);
 }
 
+// Plans are kept per op instance, keyed by the descriptor (shapes + attrs + sigma): creating one is cheap, but a kept plan
+// carries the offset-bucket hint from call to call (include/dau_conv.h, "Offset buckets"), which is what lets a layer with a
+// large max_kernel_size and small offsets run the small-offset kernels, as the reference's per-call amax does
+// (dau_conv_op.cpp:223-253).
+class PlanCache {
+  public:
+    ~PlanCache() { for (auto& kv : plans_) dau_conv_plan_destroy(kv.second); }
+    int Get(const dau_conv_desc& d, dau_conv_plan** plan) {
+        const std::string key(reinterpret_cast<const char*>(&d), sizeof(d));
+        std::lock_guard<std::mutex> lock(mu_);
+        auto it = plans_.find(key);
+        if (it != plans_.end()) { *plan = it->second; return DAU_OK; }
+        const int rc = dau_conv_plan_create(&d, plan);
+        if (rc == DAU_OK) plans_.emplace(key, *plan);
+        return rc;
+    }
+  private:
+    std::mutex mu_;
+    std::map<std::string, dau_conv_plan*> plans_;
+};
+
 class DAUConvOp : public tf::OpKernel {
   public:
     explicit DAUConvOp(tf::OpKernelConstruction* ctx) : tf::OpKernel(ctx), attrs_(ctx) {}
@@ -141,7 +164,7 @@ class DAUConvOp : public tf::OpKernel {
         hipStream_t st = StreamOf(ctx);
         const dau_conv_desc d = attrs_.Describe(x, w, HostSigma(sigma, st));
         dau_conv_plan* plan = nullptr;
-        OP_REQUIRES_OK(ctx, ToStatus(dau_conv_plan_create(&d, &plan)));
+        OP_REQUIRES_OK(ctx, ToStatus(plans_.Get(d, &plan)));
         tf::Tensor* y = nullptr;
         OP_REQUIRES_OK(ctx, ctx->allocate_output(0, tf::TensorShape({d.batch, d.out_channels, d.height, d.width}), &y));
         size_t ws_bytes = 0;
@@ -152,11 +175,11 @@ class DAUConvOp : public tf::OpKernel {
                                   mu2.flat<float>().data(), sigma.flat<float>().data(), y->flat<float>().data(),
                                   ws.flat<tf::int8>().data(), ws_bytes);
         if (rc == DAU_OK) rc = dau_conv_check_status(plan, st, ws.flat<tf::int8>().data(), nullptr);   // NaN / out-of-range offsets
-        dau_conv_plan_destroy(plan);
         OP_REQUIRES_OK(ctx, ToStatus(rc));
     }
   private:
     Attrs attrs_;
+    PlanCache plans_;
 };
 
 class DAUConvGradOp : public tf::OpKernel {
@@ -168,7 +191,7 @@ class DAUConvGradOp : public tf::OpKernel {
         hipStream_t st = StreamOf(ctx);
         const dau_conv_desc d = attrs_.Describe(x, w, HostSigma(sigma, st));
         dau_conv_plan* plan = nullptr;
-        OP_REQUIRES_OK(ctx, ToStatus(dau_conv_plan_create(&d, &plan)));
+        OP_REQUIRES_OK(ctx, ToStatus(plans_.Get(d, &plan)));
         tf::Tensor* out[5];
         for (int i = 0; i < 5; ++i) OP_REQUIRES_OK(ctx, ctx->allocate_output(i, ctx->input(i + 1).shape(), &out[i]));
         size_t ws_bytes = 0;
@@ -182,11 +205,11 @@ class DAUConvGradOp : public tf::OpKernel {
                                    out[3]->flat<float>().data(), out[4]->flat<float>().data(), ws.flat<tf::int8>().data(),
                                    ws_bytes, DAU_NEED_ALL);
         if (rc == DAU_OK) rc = dau_conv_check_status(plan, st, ws.flat<tf::int8>().data(), nullptr);
-        dau_conv_plan_destroy(plan);
         OP_REQUIRES_OK(ctx, ToStatus(rc));
     }
   private:
     Attrs attrs_;
+    PlanCache plans_;
 };
 
 }  // namespace

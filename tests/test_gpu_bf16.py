@@ -64,3 +64,18 @@ def test_bf16_needs_the_tiled_kernels():
     from dau_conv import _capi
     with pytest.raises(_capi.InvalidArgumentError):
         _capi.Plan(2, 4, 8, 2, 16, 16, flags=_capi.FLAG_USE_INTERPOLATION | _capi.FLAG_IO_BF16, algo=_capi.ALGO_DIRECT)
+
+
+def test_bf16_store_keeps_a_nan_a_nan():
+    """A NaN in the input must come out as a NaN in the bfloat16 output (the rounding add on the bits would turn some NaN
+    payloads into zero or infinity)."""
+    from dau_conv import _capi
+    N, S, F, G, H, W = 1, 1, 2, 1, 8, 8
+    plan = _capi.Plan(N, S, F, G, H, W, flags=_capi.FLAG_USE_INTERPOLATION | _capi.FLAG_IO_BF16)
+    x = torch.ones(N, S, H, W, device="cuda")
+    x[0, 0, 3, 3] = float("nan")
+    w = torch.ones(1, S, G, F, device="cuda")
+    z = torch.zeros(1, S, G, F, device="cuda")
+    y = plan.forward(x.to(torch.bfloat16), w, z, z.clone(), torch.full((1, S, G, F), 0.5, device="cuda"))
+    assert torch.isnan(y[0, 0, 3, 3]) and torch.isnan(y[0, 1, 3, 3])
+    assert torch.isfinite(y[0, 0, 0, 0])

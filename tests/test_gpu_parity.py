@@ -327,3 +327,44 @@ def test_widest_prefilter_stays_on_the_tiled_kernels():
     want = orc.backward(x, dy, w, mu1, mu2, sg)
     for t, key in zip(got, ("dx", "dw", "dmu1", "dmu2", "dsigma")):
         assert_parity(t.cpu().numpy(), want[key], key)
+
+
+def test_direct_kernels_take_more_than_65535_planes():
+    """The any-shape kernels fold (image, output channel) into grid.x: N*F beyond the 65535 limit of grid.y still runs."""
+    from dau_conv import _capi
+    rs = np.random.RandomState(2)
+    N, S, F, G, H, W = 300, 1, 256, 1, 4, 5
+    x = rs.rand(N, S, H, W).astype(np.float32)
+    w = (rs.randn(1, S, G, F) * 0.1).astype(np.float32)
+    mu1 = rs.uniform(-2, 2, (1, S, G, F)).astype(np.float32)
+    mu2 = rs.uniform(-2, 2, (1, S, G, F)).astype(np.float32)
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, algo=_capi.ALGO_DIRECT)
+    assert plan.info["algo_forward"] == _capi.ALGO_DIRECT
+    y = plan.forward(_dev(x), _dev(w), _dev(mu1), _dev(mu2), torch.full((1, S, G, F), 0.5, device="cuda"))
+    plan.check_status()
+    assert_parity(y.cpu().numpy(), orc.forward(x, w, mu1, mu2, 0.5), "y (N*F = 76800 planes)")
+
+
+def test_library_gets_the_stream_of_the_tensors_device(monkeypatch):
+    """The stream handed to the C ABI is torch's current stream of the TENSORS' device, and the call runs with that device
+    current (a model on another device than the current one must not be enqueued on the wrong stream)."""
+    from dau_conv import _capi
+    seen = {}
+    real = _capi.lib.dau_conv_forward
+
+    def spy(plan, stream, *rest):
+        seen["stream"] = stream.value if hasattr(stream, "value") else stream
+        seen["device"] = torch.cuda.current_device()
+        return real(plan, stream, *rest)
+
+    monkeypatch.setattr(_capi.lib, "dau_conv_forward", spy)
+    N, S, F, G, H, W = 1, 2, 4, 2, 8, 8
+    plan = _capi.Plan(N, S, F, G, H, W)
+    x = torch.rand(N, S, H, W, device="cuda:0")
+    p = lambda: torch.zeros(1, S, G, F, device="cuda:0")
+    side = torch.cuda.Stream(device=0)
+    with torch.cuda.stream(side):
+        plan.forward(x, p(), p(), p(), torch.full((1, S, G, F), 0.5, device="cuda:0"))
+    assert seen["stream"] == side.cuda_stream and seen["device"] == 0
+    with pytest.raises(_capi.InvalidArgumentError):
+        plan.forward(x, p().cpu(), p(), p(), p())
