@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 def _config(seed):
     rs = np.random.RandomState(1000 + seed)
-    k = int(rs.choice([9, 9, 9, 17, 17, 33, 65]))
+    k = int(rs.choice([9, 9, 9, 17, 17, 33, 65, 37, 41, 49]))
     H = int(rs.randint(5, 80)); W = int(rs.randint(5, 80))
     if seed % 7 == 0:
         H, W = int(rs.choice([56, 64, 96, 112])), int(rs.choice([56, 64, 72, 120]))
@@ -74,4 +74,49 @@ def test_random_configuration(seed):
     tag = "seed%d %s " % (seed, {q: c[q] for q in ("N", "S", "F", "G", "H", "W", "k", "sigma", "ignore")})
     assert_parity(y.cpu().numpy(), want_y, tag + "y")
     for t, key in zip(got, ("dx", "dw", "dmu1", "dmu2", "dsigma")):
+        assert_parity(t.cpu().numpy(), want[key], tag + key)
+    # the first forward ran the static bucket (no hint yet); this one runs the bucket the offsets need
+    y2 = plan.forward(dev(x), dev(w), dev(mu1), dev(mu2), sig)
+    plan.check_status()
+    assert_parity(y2.cpu().numpy(), want_y, tag + "y (hinted bucket)")
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DAU_FUZZ_DENSE_SEEDS", "40"))))
+def test_random_configuration_dense_bf16(seed):
+    """The same sweep for bfloat16 layers with DAU_FLAG_DENSE_BF16 (offsets within +-4 under kernels 9 and 17): y and dx at
+    the bf16 bar, parameter gradients at the fp32 bar (they keep the exact path)."""
+    from dau_conv import _capi
+    c = _config(seed)
+    rs = np.random.RandomState(7000 + seed)
+    N, S, F, G, H, W = (c[q] for q in ("N", "S", "F", "G", "H", "W"))
+    k = 9 if seed % 3 else 17
+    xb = torch.from_numpy(rs.rand(N, S, H, W).astype(np.float32)).to(torch.bfloat16)
+    dyb = torch.from_numpy(rs.randn(N, F, H, W).astype(np.float32)).to(torch.bfloat16)
+    w = (rs.randn(1, S, G, F) * 0.1).astype(np.float32)
+    m = min(c["m"], 4.0)
+    mu1 = np.clip(rs.uniform(-m, m, (1, S, G, F)), -4.0, 4.0).astype(np.float32)
+    mu2 = np.clip(rs.uniform(-m, m, (1, S, G, F)), -4.0, 4.0).astype(np.float32)
+    if c["flags"]["single_dim_kernel"]:
+        mu2[:] = 0.0
+    fl = _capi.FLAG_IO_BF16 | _capi.FLAG_DENSE_BF16
+    if c["flags"]["use_interpolation"]: fl |= _capi.FLAG_USE_INTERPOLATION
+    if c["flags"]["single_dim_kernel"]: fl |= _capi.FLAG_SINGLE_DIM_KERNEL
+    if c["flags"]["forbid_positive_dim1"]: fl |= _capi.FLAG_FORBID_POSITIVE_DIM1
+    sigma = c["sigma"] if c["sigma"] <= 0.8 else 0.5
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, number_units_ignore=c["ignore"], flags=fl, sigma_hint=sigma)
+    assert plan.info["gather_dense_bf16"] == 1
+    dev = lambda a: torch.from_numpy(a).cuda()
+    sig = torch.full((1, S, G, F), sigma, device="cuda")
+    for _ in range(2):                                  # kernel 17: the second round is the hinted (dense) one
+        y = plan.forward(xb.cuda(), dev(w), dev(mu1), dev(mu2), sig)
+        got = plan.backward(xb.cuda(), dyb.cuda(), dev(w), dev(mu1), dev(mu2), sig)
+        plan.check_status()
+    kw = dict(ignore=c["ignore"], **c["flags"])
+    x32, dy32 = xb.float().numpy(), dyb.float().numpy()
+    want_y = orc.forward(x32, w, mu1, mu2, sigma, **kw)
+    want = orc.backward(x32, dy32, w, mu1, mu2, sigma, **kw)
+    tag = "dense seed%d %s " % (seed, {q: c[q] for q in ("N", "S", "F", "G", "H", "W", "ignore")})
+    assert_parity(y.float().cpu().numpy(), want_y, tag + "y", rel=2e-2, floor=4e-3)
+    assert_parity(got[0].float().cpu().numpy(), want["dx"], tag + "dx", rel=2e-2, floor=4e-3)
+    for t, key in zip(got[1:], ("dw", "dmu1", "dmu2", "dsigma")):
         assert_parity(t.cpu().numpy(), want[key], tag + key)
