@@ -141,6 +141,7 @@ DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one
         // rounds halve the rounding error of the parameter gradients against the double-accumulating oracle.
         const int nrounds = rounds > 0 ? rounds : (binned ? 8 : 16);
         int chunks = (256 * nrounds + (binned ? per_chunk - 1 : 0)) / per_chunk;
+        if (!binned && chunks > 64) chunks = 64;            // the reduction pass reads every chunk's slab: keep it cheap on small layers
         if (chunks > g.items) chunks = g.items;
         if (chunks < 1) chunks = 1;
         const int per = (g.items + chunks - 1) / chunks;
