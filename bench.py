@@ -74,6 +74,9 @@ def parse_args():
                     help="storage type of x, y, dy, dx (BASELINE config 2 names bf16); arithmetic is fp32 either way")
     ap.add_argument("--dense", action="store_true",
                     help="with --io bf16: DAU_FLAG_DENSE_BF16 (gather-sum passes of calls with |mu| <= 4 as a densified bf16 MFMA GEMM)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture one step into a HIP graph and time its replays (single rank; no per-kernel events, so the "
+                         "line carries no roofline object: a launch-overhead probe for the small workloads)")
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 direct, 2 tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-layer", action="store_true", help="skip the layer-level (DAUConv2d + autograd) timing")
@@ -268,13 +271,31 @@ def main():
         step()
     plan.check_status()
     fence()
-    plan.profile_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = plan.profile_end()
+    if args.graph and not use_dist:
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            step()                                  # workspace and hint on the capture stream
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            step()
+        for _ in range(2):
+            graph.replay()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            graph.replay()
+        fence()
+        elapsed = time.perf_counter() - t0
+        prof = {}
+    else:
+        plan.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        prof = plan.profile_end()
     if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -374,6 +395,7 @@ def main():
                               % (4 * S * G * F)) if use_dist else None),
                    config=dict(workload=wl["label"] + (" [bf16 activations in HBM]" if args.io == "bf16" else "") +
                                (" [gather-sum passes as densified bf16 MFMA GEMM]" if dense else "") +
+                               (" [one step captured into a HIP graph, replays timed]" if args.graph and not use_dist else "") +
                                ("" if backend == "nccl" else " [REHEARSAL: %s backend, ranks share GPUs]" % backend),
                                global_batch=N * world, parallelism="dp%d" % world,
                                algo_forward=plan.info["algo_forward"], algo_backward=plan.info["algo_backward"],

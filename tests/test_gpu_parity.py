@@ -368,3 +368,39 @@ def test_library_gets_the_stream_of_the_tensors_device(monkeypatch):
     assert seen["stream"] == side.cuda_stream and seen["device"] == 0
     with pytest.raises(_capi.InvalidArgumentError):
         plan.forward(x, p().cpu(), p(), p(), p())
+
+
+def test_forward_backward_capture_into_a_hip_graph():
+    """The calls only enqueue work on the caller's stream (kernels and one 16-byte memset; the launch attributes were set
+    by the first call), so a warmed-up forward + backward can be captured into a HIP graph and replayed: same results as
+    the eager calls, also after the inputs changed in place.  The offset-bucket candidates are frozen at capture time;
+    the device-side guards still pick the set the replay's offsets need."""
+    from dau_conv import _capi
+    rs = np.random.RandomState(8)
+    N, S, F, G, H, W, k = 4, 12, 24, 4, 28, 28, 17
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, sigma_hint=0.5)
+    x = torch.rand(N, S, H, W, device="cuda")
+    dy = torch.randn(N, F, H, W, device="cuda")
+    w = torch.randn(1, S, G, F, device="cuda") * 0.1
+    mu1 = (torch.rand(1, S, G, F, device="cuda") * 2 - 1) * 3.0
+    mu2 = (torch.rand(1, S, G, F, device="cuda") * 2 - 1) * 3.0
+    sigma = torch.full((1, S, G, F), 0.5, device="cuda")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(2):                                   # warm-up on the capture stream: workspace, attributes, hint
+            plan.forward(x, w, mu1, mu2, sigma); plan.backward(x, dy, w, mu1, mu2, sigma)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        y = plan.forward(x, w, mu1, mu2, sigma)
+        grads = plan.backward(x, dy, w, mu1, mu2, sigma)
+    for trial in range(2):
+        if trial == 1:                                       # new inputs and LARGER offsets in place (beyond the hinted bucket)
+            x.copy_(torch.rand_like(x)); mu1.mul_(2.4); mu2.mul_(-2.4)
+        graph.replay()
+        torch.cuda.synchronize()
+        want_y = orc.forward(x.cpu().numpy(), w.cpu().numpy(), mu1.cpu().numpy(), mu2.cpu().numpy(), 0.5)
+        want = orc.backward(x.cpu().numpy(), dy.cpu().numpy(), w.cpu().numpy(), mu1.cpu().numpy(), mu2.cpu().numpy(), 0.5)
+        assert_parity(y.cpu().numpy(), want_y, "graph replay %d: y" % trial)
+        for t, key in zip(grads, ("dx", "dw", "dmu1", "dmu2", "dsigma")):
+            assert_parity(t.cpu().numpy(), want[key], "graph replay %d: %s" % (trial, key))
