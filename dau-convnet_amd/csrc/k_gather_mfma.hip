@@ -94,6 +94,9 @@ const Variant kVariants[] = {
     // output channels per workgroup sharing the bigger plane.  Bucket 24 therefore needs no offset windows.
     {4, 4, 72, 0, 2, 1, 0, 4, 0},       // 16: 31 pixel patches, R <= 20
     {4, 4, 104, 0, 1, 1, 0, 8, 0},      // 17: 31 pixel patches, R <= 28, 8 channels
+    {4, 4, 40, 0, 1, 1, 0, 8, 0},       // 18: one 25..31 pixel image, eight channels on its plane (28x28 at 512 channels:
+                                        //     73.7 / 69.4 TF against 71.1 / 67.8 for the three stacked images of row 12)
+    {4, 4, 40, 0, 2, 2, 13312, 4, 2},   // 19: two stacked 25..31 pixel images (tuning alternative, DAU_GATHER_VARIANT=19: no gain)
 };
 
 // one (channel block, input channel) slice of the packed unit table: [G slots][fb channels][8 dwords]; window passes
@@ -126,6 +129,7 @@ Geometry make_geometry(int H, int W, int R, int G, int N, int Cout, int only = -
     for (int i = 0; i < (int)(sizeof(kVariants) / sizeof(kVariants[0])); ++i) {
         const Variant& v = kVariants[i];
         if (only >= 0 && i != only) continue;
+        if (only < 0 && v.tuning == 2) continue;                                      // explicit request only
         if (only < 0 && v.tuning && v.split != want_split) continue;
         int ph, pw, cols, rows;
         if (v.edge) {
@@ -752,6 +756,8 @@ void dispatch_variant(int variant, hipStream_t st, const GatherArgs* a, int grid
         case 15: launch_variant<GatherTraits<1, 1, 40, false, 1, 8, 5120, 16>>(st, a, grid, lds); break;
         case 16: launch_variant<GatherTraits<4, 4, 72, false, 2>>(st, a, grid, lds); break;
         case 17: launch_variant<GatherTraits<4, 4, 104, false, 1, 1, 0, 8>>(st, a, grid, lds); break;
+        case 18: launch_variant<GatherTraits<4, 4, 40, false, 1, 1, 0, 8>>(st, a, grid, lds); break;
+        case 19: launch_variant<GatherTraits<4, 4, 40, false, 2, 2, 13312, 4>>(st, a, grid, lds); break;
         default: break;
     }
 }
