@@ -62,12 +62,13 @@ struct Geometry {
     int variant;              // row of kVariants, -1: no instantiated kernel fits
     int sk;                   // (image pair, patch) planes stacked per workgroup
     int fb;                   // output channels per workgroup
+    int nb;                   // plane buffers in LDS (2, or 3 for the lagged kernels)
     int strip_pitch;          // EDGE: rows of the transposed strip (columns pw .. pw+2R of the plane, column-major)
     size_t strip_off;         // byte offset of the strip inside a staged plane
     size_t plane_bytes;       // padded to 1 KiB (one global_load_lds wave instruction)
 };
 
-struct Variant { int tx, ty, pitch, edge, split, sk, plane_bytes, fb, tuning; };
+struct Variant { int tx, ty, pitch, edge, split, sk, plane_bytes, fb, tuning, nb = 2; };
 // instantiated kernels (add rows here and in the dispatch of tiled_gather_run)
 const Variant kVariants[] = {
     {7, 7, 72, 1, 2, 1, 0, 4, 0},       // 0: 56x56 patches, R=4
@@ -97,6 +98,7 @@ const Variant kVariants[] = {
     {4, 4, 40, 0, 1, 1, 0, 8, 0},       // 18: one 25..31 pixel image, eight channels on its plane (28x28 at 512 channels:
                                         //     73.7 / 69.4 TF against 71.1 / 67.8 for the three stacked images of row 12)
     {4, 4, 40, 0, 2, 2, 13312, 4, 2},   // 19: two stacked 25..31 pixel images (tuning alternative, DAU_GATHER_VARIANT=19: no gain)
+    {7, 7, 72, 1, 2, 1, 0, 4, 2, 3},    // 20: row 0 with three plane buffers and lagged partner waves (DAU_GATHER_VARIANT=20)
 };
 
 // one (channel block, input channel) slice of the packed unit table: [G slots][fb channels][8 dwords]; window passes
@@ -144,7 +146,8 @@ Geometry make_geometry(int H, int W, int R, int G, int N, int Cout, int only = -
         const size_t plane = round_up(((size_t)rows * v.pitch + (v.edge ? (size_t)(2 * R + 1) * rows : 0)) * 8, 1024);
         if (v.plane_bytes && plane != (size_t)v.plane_bytes) continue;
         // two buffers of sk planes + two unit slices must fit the 160 KiB of LDS
-        if (2 * v.sk * plane + 2 * ut_stride_bytes(G, v.fb, binned) > 160 * 1024) continue;
+        if (v.nb * v.sk * plane + v.nb * ut_stride_bytes(G, v.fb, binned) > 160 * 1024) continue;
+        if (v.nb == 3 && binned) continue;                                           // lagged kernels: every channel has G units
         const int npx = (W + pw - 1) / pw, npy = (H + ph - 1) / ph;
         const long planes = (long)((N + 1) / 2) * npx * npy, groups = (planes + v.sk - 1) / v.sk;
         if (never_stack && v.sk > 1) continue;
@@ -160,7 +163,7 @@ Geometry make_geometry(int H, int W, int R, int G, int N, int Cout, int only = -
         if (g.variant >= 0 && cost >= best) continue;
         best = cost;
         g.variant = i; g.ph = ph; g.pw = pw; g.npx = npx; g.npy = npy; g.rows = rows; g.cols = cols; g.pitch = v.pitch;
-        g.tx = v.tx; g.ty = v.ty; g.edge = v.edge; g.sk = v.sk; g.fb = v.fb;
+        g.tx = v.tx; g.ty = v.ty; g.edge = v.edge; g.sk = v.sk; g.fb = v.fb; g.nb = v.nb;
     }
     }
     if (g.variant < 0) return g;
@@ -384,9 +387,15 @@ struct GatherArgs {
 //          workgroup (small feature maps: more tiles per wave against the per-channel fixed cost).  PB = 0 with SK = 1:
 //          plane size taken at run time.
 // FB     : output channels per workgroup (one wave, or SPLIT waves, each)
-template <int TX_, int TY_, int PITCH_, bool EDGE_, int SPLIT_, int SK_ = 1, int PB_ = 0, int FB_ = kFB>
+// NB     : plane buffers in LDS.  2: every wave gathers channel c between barriers c and c+1.  3 ("lagged"): the second
+//          half of the waves (the SIMD partners of the first half) runs ONE UNIT behind -- between barriers c and c+1 they
+//          gather the last unit of channel c-1 and all but the last unit of channel c -- so that after a barrier they start
+//          with tile reads whose addresses they already hold while their partners fetch table entries, and the two waves
+//          of a SIMD do not sit in their start-up at the same time (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
+template <int TX_, int TY_, int PITCH_, bool EDGE_, int SPLIT_, int SK_ = 1, int PB_ = 0, int FB_ = kFB, int NB_ = 2>
 struct GatherTraits {
-    static constexpr int TX = TX_, TY = TY_, PITCH = PITCH_, SPLIT = SPLIT_, SK = SK_, PB = PB_, FB = FB_;
+    static constexpr int TX = TX_, TY = TY_, PITCH = PITCH_, SPLIT = SPLIT_, SK = SK_, PB = PB_, FB = FB_, NB = NB_;
+    static constexpr bool LAGGED = NB_ == 3;
     static constexpr bool EDGE = EDGE_;
     static constexpr int kRegular = TX * TY;
     // the extra row and column of Z share one tile when they fit its 64 lanes (patches up to 24 pixels)
@@ -475,16 +484,23 @@ __device__ __forceinline__ void group_batches(f4 (&acc)[KP][2], f2 (&xv)[2][kBat
     if constexpr (more) group_batches<T, FIRST, COUNT, KP, U, FB + 1>(acc, xv, wv, addr, addr_e0, addr_e1);
 }
 
-// ut_addr: LDS address of this lane's slot in the first unit's table entry; entries are unit_pitch bytes apart.
+// ut_addr0 / pbase0: LDS address of this lane's slot in the FIRST unit's table entry and the plane buffer that unit reads;
+// ut_addr / pbase: the same for the group's second unit, the following ones are unit_pitch bytes apart.  Ordinarily the
+// first unit is just the entry before the second; for a lagged wave's first group of a channel it is the previous
+// channel's last unit, in the previous channel's buffers (all four values are wave-uniform run-time numbers: one code path).
 template <class T, int PART, int KP, int U>
-__device__ __forceinline__ void unit_group(f4 (&acc)[KP][2], unsigned ut_addr, unsigned unit_pitch, unsigned pbase,
-                                           unsigned lane_base, unsigned ebase0, unsigned ebase1) {
+__device__ __forceinline__ void unit_group(f4 (&acc)[KP][2], unsigned ut_addr0, unsigned pbase0, unsigned ut_addr,
+                                           unsigned unit_pitch, unsigned pbase, unsigned lane_base, unsigned ebase0,
+                                           unsigned ebase1) {
     constexpr int first = PART * T::kPerPart;
     constexpr int count = (first + KP <= T::kTiles) ? KP : (T::kTiles > first ? T::kTiles - first : 0);
     if constexpr (count > 0) {
         f2 wo[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) asm volatile("ds_read_b64 %0, %1" : "=v"(wo[u]) : "v"(ut_addr + u * unit_pitch) : "memory");
+        for (int u = 0; u < U; ++u) {
+            const unsigned ua = u == 0 ? ut_addr0 : ut_addr + (u - 1) * unit_pitch;
+            asm volatile("ds_read_b64 %0, %1" : "=v"(wo[u]) : "v"(ua) : "memory");
+        }
         lds_wait<0>();
         float wv[U];
         unsigned addr[U], addr_e0[U], addr_e1[U];
@@ -493,8 +509,9 @@ __device__ __forceinline__ void unit_group(f4 (&acc)[KP][2], unsigned ut_addr, u
             wv[u] = wo[u].x;
             // lanes 0,1 of every quad hold the plane displacement, lanes 2,3 the strip displacement: broadcast both
             const unsigned oraw = __float_as_uint(wo[u].y);
-            const unsigned off = (unsigned)__builtin_amdgcn_mov_dpp((int)oraw, 0x00, 0xf, 0xf, true) + pbase;
-            const unsigned offt = (unsigned)__builtin_amdgcn_mov_dpp((int)oraw, 0xAA, 0xf, 0xf, true) + pbase;
+            const unsigned pb = u == 0 ? pbase0 : pbase;
+            const unsigned off = (unsigned)__builtin_amdgcn_mov_dpp((int)oraw, 0x00, 0xf, 0xf, true) + pb;
+            const unsigned offt = (unsigned)__builtin_amdgcn_mov_dpp((int)oraw, 0xAA, 0xf, 0xf, true) + pb;
             addr[u] = lane_base + off;
             if constexpr (T::kMergeEdge) {
                 // one edge tile: ebase1 is a lane mask, set for the lanes that walk the column strip
@@ -513,7 +530,10 @@ __device__ __forceinline__ void unit_group(f4 (&acc)[KP][2], unsigned ut_addr, u
 // LDS immediates are compile-time constants; every wave runs the same number of barriers).
 template <class T, int PART>
 __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int lane, int wave, int fi) {
+    // lagged kernels: the waves of the second half (SIMD partners of the first) run one unit behind (GatherTraits::NB)
+    const bool lag = T::LAGGED && wave >= T::kWaves / 2;
     constexpr int KP = T::kPerPart;
+    constexpr int NB = T::NB;
     constexpr int TX = T::TX, TY = T::TY, PITCH = T::PITCH, SK = T::SK;
     constexpr bool EDGE = T::EDGE;
 
@@ -560,7 +580,7 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
     const unsigned plane_bytes = T::PB ? (unsigned)T::PB : a.plane_bytes, ut_stride = a.ut_stride;
     const unsigned buf_bytes = SK * plane_bytes;
     const char* src_units = a.packed + (size_t)fb * a.Cin * ut_stride;
-    const unsigned ut_base = 2 * buf_bytes;
+    const unsigned ut_base = NB * buf_bytes;
 
     auto issue = [&](int c, int buf) {
         const unsigned pieces = plane_bytes >> 10;
@@ -585,11 +605,12 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
     for (int i = 0; i < KP; ++i) { acc[i][0] = f4{0, 0, 0, 0}; acc[i][1] = f4{0, 0, 0, 0}; }
 
     issue(0, 0);
-    for (int c = 0; c < a.Cin; ++c) {
-        const int buf = c & 1;
+    int buf = 0, pbuf = NB - 1;        // buffers of channel c and of channel c - 1
+    for (int c = 0; c < a.Cin; ++c, pbuf = buf, buf = (buf + 1 == NB ? 0 : buf + 1)) {
+        const int nbuf = buf + 1 == NB ? 0 : buf + 1;
 #ifndef DAU_DIAG_NOBARRIER
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // plane c is in LDS for everyone; everyone is done reading plane c-1
+        __syncthreads();   // plane c is in LDS for everyone; everyone is done reading plane c-1 (lagged kernels: c-2)
 #endif
 #ifdef DAU_DIAG_FUSED_BLUR
         // Timing diagnosis (results are garbage): what filling plane c+1 INSIDE this kernel would add to a wave's
@@ -602,10 +623,10 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
             const char* us = src_units + (size_t)(c + 1) * ut_stride;
             for (unsigned piece = wave; piece < (ut_stride >> 10); piece += T::kWaves)
                 __builtin_amdgcn_global_load_lds((glb_ptr_t)(us + (size_t)piece * 1024 + lane * 16),
-                                                 (lds_ptr_t)(smem + ut_base + (buf ^ 1) * ut_stride + piece * 1024), 16, 0, 0);
+                                                 (lds_ptr_t)(smem + ut_base + nbuf * ut_stride + piece * 1024), 16, 0, 0);
             constexpr int kRawRounds = (71 * 71 + 64 * T::kWaves - 1) / (64 * T::kWaves);       // positions per lane, raw window
             constexpr int kOutRounds = (65 * 65 + 64 * T::kWaves - 1) / (64 * T::kWaves);       // positions per lane, staged plane
-            const unsigned wr = (buf ^ 1) * buf_bytes + lane * 8, rd = buf * buf_bytes + lane * 8;
+            const unsigned wr = nbuf * buf_bytes + lane * 8, rd = buf * buf_bytes + lane * 8;
             const char* gsrc = a.staged + (size_t)lane * 4;
             f2 raw[kRawRounds];
 #pragma unroll
@@ -636,7 +657,7 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
             }
         }
 #else
-        if (c + 1 < a.Cin && !((a.debug & 1) && c >= 1)) issue(c + 1, buf ^ 1);
+        if (c + 1 < a.Cin && !((a.debug & 1) && c >= 1)) issue(c + 1, nbuf);
 #endif
         const unsigned pbase = buf * buf_bytes;
         const unsigned ut_addr = ut_base + buf * ut_stride + (fi * kUnitDwords + (lane & 3) * 2) * 4;
@@ -649,15 +670,35 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
                          : "=v"(cw) : "v"(ut_base + buf * ut_stride + (unsigned)(a.G * T::FB * kUnitDwords + fi) * 4) : "memory");
             ng = __builtin_amdgcn_readfirstlane((int)cw);
         }
-        int g = 0;
-        for (; g + 4 <= ng; g += 4)
-            unit_group<T, PART, KP, 4>(acc, ut_addr + g * unit_pitch, unit_pitch, pbase, lane_base, ebase0, ebase1);
-        if (g + 2 <= ng) {
-            unit_group<T, PART, KP, 2>(acc, ut_addr + g * unit_pitch, unit_pitch, pbase, lane_base, ebase0, ebase1);
-            g += 2;
+        // this interval's units: the first one (a0, p0), then consecutive entries of THIS channel from `rest` on
+        int n = ng;
+        unsigned a0 = ut_addr, p0 = pbase, rest = ut_addr + unit_pitch;
+        if (lag) {
+            if (c == 0) {
+                n = ng - 1;                    // units 0 .. ng-2; the last one waits for the next interval
+            } else {                           // [last unit of channel c-1] + units 0 .. ng-2 of channel c
+                a0 = ut_base + pbuf * ut_stride + (fi * kUnitDwords + (lane & 3) * 2) * 4 + (ng - 1) * unit_pitch;
+                p0 = pbuf * buf_bytes;
+                rest = ut_addr;
+            }
         }
-        if (g < ng)
-            unit_group<T, PART, KP, 1>(acc, ut_addr + g * unit_pitch, unit_pitch, pbase, lane_base, ebase0, ebase1);
+        int g = 0;
+        for (; g + 4 <= n; g += 4) {
+            unit_group<T, PART, KP, 4>(acc, a0, p0, rest, unit_pitch, pbase, lane_base, ebase0, ebase1);
+            a0 = rest + 3 * unit_pitch; p0 = pbase; rest = a0 + unit_pitch;
+        }
+        if (g + 2 <= n) {
+            unit_group<T, PART, KP, 2>(acc, a0, p0, rest, unit_pitch, pbase, lane_base, ebase0, ebase1);
+            g += 2; a0 = rest + unit_pitch; p0 = pbase; rest = a0 + unit_pitch;
+        }
+        if (g < n)
+            unit_group<T, PART, KP, 1>(acc, a0, p0, rest, unit_pitch, pbase, lane_base, ebase0, ebase1);
+    }
+    if (lag) {
+        // the last unit of the last channel (its plane stays in LDS: the partners wait at the epilogue's first barrier)
+        constexpr unsigned unit_pitch = T::FB * kUnitDwords * 4;
+        const unsigned a0 = ut_base + pbuf * ut_stride + (fi * kUnitDwords + (lane & 3) * 2) * 4 + (a.G - 1) * unit_pitch;
+        unit_group<T, PART, KP, 1>(acc, a0, pbuf * buf_bytes, a0, unit_pitch, pbuf * buf_bytes, lane_base, ebase0, ebase1);
     }
 
     // ---- epilogue: out[p] = Z0[p] + Z1[p+(0,1)] + Z2[p+(1,0)] + Z3[p+(1,1)] through LDS ---------------
@@ -758,6 +799,7 @@ void dispatch_variant(int variant, hipStream_t st, const GatherArgs* a, int grid
         case 17: launch_variant<GatherTraits<4, 4, 104, false, 1, 1, 0, 8>>(st, a, grid, lds); break;
         case 18: launch_variant<GatherTraits<4, 4, 40, false, 1, 1, 0, 8>>(st, a, grid, lds); break;
         case 19: launch_variant<GatherTraits<4, 4, 40, false, 2, 2, 13312, 4>>(st, a, grid, lds); break;
+        case 20: launch_variant<GatherTraits<7, 7, 72, true, 2, 1, 0, 4, 3>>(st, a, grid, lds); break;
         default: break;
     }
 }
@@ -782,7 +824,7 @@ int blur_pack_bands(const Geometry& g, int k) {
 }
 
 size_t lds_bytes(const TiledConfig& c, const Geometry& g) {
-    const size_t main_b = 2 * g.sk * g.plane_bytes + 2 * ut_stride_bytes(c.G, g.fb, g.nwin1 > 1);
+    const size_t main_b = (size_t)g.nb * g.sk * g.plane_bytes + g.nb * ut_stride_bytes(c.G, g.fb, g.nwin1 > 1);
     const size_t zpitch = g.pw + 2;
     const size_t epi_b = (size_t)g.sk * 2 /*kEpiF*/ * 4 * (g.ph + 1) * zpitch * 4;
     return main_b > epi_b ? main_b : epi_b;

@@ -260,6 +260,13 @@ def test_seeded_shapes_against_c_oracle(shape, algo):
     dict(N=2, W=64, H=64, S=4, F=16, G=5, k=49, m=23.5, variant=17, stack=1, patch=32),
     dict(N=3, W=40, H=90, S=3, F=9, G=3, k=65, m=31.5, variant=17, stack=1, patch=32),      # bucket 32 in one pass
     dict(N=2, W=100, H=37, S=2, F=20, G=9, k=65, m=31.5, variant=17, stack=1, patch=32),    # nine units: windows
+    # three plane buffers, partner waves one unit behind (row 20): every unit-count class of its group logic
+    dict(N=4, W=56, H=56, S=9, F=12, G=4, k=9, m=3, variant=20, stack=1, patch=56),
+    dict(N=3, W=50, H=41, S=5, F=7, G=1, k=9, m=3, variant=20, stack=1, patch=56),
+    dict(N=2, W=56, H=56, S=4, F=8, G=2, k=9, m=3, variant=20, stack=1, patch=56),
+    dict(N=2, W=56, H=56, S=3, F=9, G=3, k=9, m=3, variant=20, stack=1, patch=56),
+    dict(N=2, W=80, H=56, S=1, F=8, G=6, k=9, m=3, variant=20, stack=1, patch=56),
+    dict(N=2, W=56, H=56, S=2, F=4, G=9, k=9, m=3, variant=20, stack=1, patch=56),
 ])
 def test_stacked_gather_variants(shape, monkeypatch):
     from dau_conv import _capi
