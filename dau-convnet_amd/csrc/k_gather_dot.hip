@@ -781,7 +781,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
         }
         if (!two && item + 1 < item1) {
             __syncthreads();            // every wave is done with the only tile
-            issue(item + 1, 0);
+            if (!(a.debug & 2)) issue(item + 1, 0);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
