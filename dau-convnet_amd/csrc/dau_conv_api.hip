@@ -54,6 +54,14 @@ struct Carver {
     }
 };
 
+// image n0 of an activation tensor whose elements are esize bytes (float32, or bfloat16 behind the float* of the ABI)
+inline const float* slab_ptr(const float* base, size_t elements, size_t esize) {
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + elements * esize);
+}
+inline float* slab_ptr(float* base, size_t elements, size_t esize) {
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(base) + elements * esize);
+}
+
 // unit_testing edge rule of the numpy oracle (dau_conv_test.py:110-136)
 int edge_disabled(int size) {
     if (size >= 64) return size % 64 == 0;
@@ -76,6 +84,11 @@ struct BucketSet {
     // DAU_FLAG_DENSE_BF16, bucket 4 only: the gather-sum passes run as a densified bf16 implicit GEMM (k_dense_bf16.hip)
     bool dense_ok = false;
     DenseConfig dense_fwd, dense_dx;
+    // Batch slabs.  Every pass stages its whole input before it gathers; where that staged copy would exceed the workspace
+    // budget (DAU_WORKSPACE_BUDGET_GB at plan creation, default 12: only the 512 x 512 configurations get there) the pass
+    // runs slab by slab over the batch -- the configs above are made for `slab_*` images, the passes loop -- so that the
+    // workspace holds one slab's staged copy.  Forward and dx are per-image; the parameter sums add up over the slabs.
+    int slab_gather = 0, slab_dot = 0;     // images per slab (the whole batch unless the budget says otherwise)
 };
 constexpr int kBuckets[] = {4, 8, 16, 18, 20, 24, 32};
 constexpr int kNumBuckets = 7;
@@ -312,16 +325,42 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
 
     const Shape& s = p->sh;
     const bool bf16 = (desc->flags & DAU_FLAG_IO_BF16) != 0;
+    const char* budget_env = getenv("DAU_WORKSPACE_BUDGET_GB");
+    const double budget_bytes = (budget_env ? atof(budget_env) : 12.0) * 1e9;
     for (int b : kBuckets) {
         if (b > bucket) break;
         BucketSet& bs = p->sets[p->nsets++];
         bs.bucket = b;
-        bs.fwd_ok = tiled_gather_configure(s.N, s.S, s.F, s.G, s.H, s.W, b, blur_k, bf16, &bs.tiled_fwd) &&
-                    tiled_gather_configure(s.N, s.F, s.S, s.G, s.H, s.W, b, blur_k, bf16, &bs.tiled_dx);
-        bs.dot_ok = tiled_dot_configure(s, b, blur_k, bf16, desc->number_units_ignore, &bs.tiled_dot);
-        bs.dense_ok = (desc->flags & DAU_FLAG_DENSE_BF16) && bs.fwd_ok && desc->algo != DAU_ALGO_DIRECT &&
-                      dense_gather_configure(s.N, s.S, s.F, s.G, s.H, s.W, b, blur_k, bf16, &bs.dense_fwd) &&
-                      dense_gather_configure(s.N, s.F, s.S, s.G, s.H, s.W, b, blur_k, bf16, &bs.dense_dx);
+        // slab candidates: the whole batch, then its even divisors (image pairs stay together), largest first
+        const bool want_dense = (desc->flags & DAU_FLAG_DENSE_BF16) && desc->algo != DAU_ALGO_DIRECT;
+        auto configure_gather = [&](int n) {
+            bs.fwd_ok = tiled_gather_configure(n, s.S, s.F, s.G, s.H, s.W, b, blur_k, bf16, &bs.tiled_fwd) &&
+                        tiled_gather_configure(n, s.F, s.S, s.G, s.H, s.W, b, blur_k, bf16, &bs.tiled_dx);
+            bs.dense_ok = want_dense && bs.fwd_ok &&
+                          dense_gather_configure(n, s.S, s.F, s.G, s.H, s.W, b, blur_k, bf16, &bs.dense_fwd) &&
+                          dense_gather_configure(n, s.F, s.S, s.G, s.H, s.W, b, blur_k, bf16, &bs.dense_dx);
+            size_t need = 0;
+            if (bs.fwd_ok) need = std::max(tiled_gather_workspace_bytes(bs.tiled_fwd), tiled_gather_workspace_bytes(bs.tiled_dx));
+            if (bs.dense_ok) need = std::max(need, std::max(dense_gather_workspace_bytes(bs.dense_fwd), dense_gather_workspace_bytes(bs.dense_dx)));
+            return need;
+        };
+        auto configure_dot = [&](int n) {
+            Shape sn = s; sn.N = n;
+            bs.dot_ok = tiled_dot_configure(sn, b, blur_k, bf16, desc->number_units_ignore, &bs.tiled_dot);
+            return bs.dot_ok ? tiled_dot_workspace_bytes(bs.tiled_dot) : (size_t)0;
+        };
+        auto pick_slab = [&](auto&& configure) {
+            int chosen = s.N;
+            for (int n = s.N; n >= 2; --n) {
+                if (s.N % n || (n != s.N && (n & 1))) continue;
+                chosen = n;
+                if ((double)configure(n) <= budget_bytes) break;
+            }
+            configure(chosen);
+            return chosen;
+        };
+        bs.slab_gather = pick_slab(configure_gather);
+        bs.slab_dot = pick_slab(configure_dot);
     }
     if ((desc->flags & DAU_FLAG_DENSE_BF16) && !bf16) {
         delete p;
@@ -407,6 +446,8 @@ int dau_conv_plan_get_info(const dau_conv_plan* plan, dau_conv_plan_info* info) 
     info->gather_windows = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.windows : 0;
     info->bucket_sets = plan->dynamic ? plan->nsets : 1;
     info->gather_dense_bf16 = plan->sets[0].dense_ok ? 1 : 0;
+    info->batch_slab_gather = plan->top().slab_gather;
+    info->batch_slab_dot = plan->top().slab_dot;
     return DAU_OK;
 }
 
@@ -435,18 +476,24 @@ int dau_conv_forward(const dau_conv_plan* p, void* stream, const float* x, const
         Candidate cand[2];
         const int ncand = pick_candidates(p, ws.status, 0, cand);
         if (p->profiling) ++p->prof_passes[0];
+        const size_t esize = (p->d.flags & DAU_FLAG_IO_BF16) ? 2 : 4;
         for (int ci = 0; ci < ncand; ++ci) {
-            if (cand[ci].set->dense_ok) {                                  // bf16 layer, offsets within +-4: dense implicit GEMM
-                dense_gather_prepare(st, cand[ci].set->dense_fwd, x, ws.filters, false, ws.table, ws.tiled, cand[ci].guard);
-                ProfScope prof(p, 0, st);
-                dense_gather_run(st, cand[ci].set->dense_fwd, y, ws.tiled, cand[ci].guard);
-                continue;
-            }
-            const TiledConfig& cfg = cand[ci].set->tiled_fwd;
-            for (int window = 0; window < tiled_gather_windows(cfg); ++window) {   // one pass unless the bucket is 24 or 32
-                tiled_gather_prepare(st, cfg, x, ws.filters, false, ws.table, ws.tiled, window, cand[ci].guard);
-                ProfScope prof(p, 0, st);
-                tiled_gather_run(st, cfg, y, ws.tiled, window > 0, cand[ci].guard);
+            const BucketSet& bs = *cand[ci].set;
+            for (int n0 = 0; n0 < s.N; n0 += bs.slab_gather) {             // one slab unless the staged copy exceeds the budget
+                const float* xs = slab_ptr(x, (size_t)n0 * s.S * s.H * s.W, esize);
+                float* ys = slab_ptr(y, (size_t)n0 * s.F * s.H * s.W, esize);
+                if (bs.dense_ok) {                                         // bf16 layer, offsets within +-4: dense implicit GEMM
+                    dense_gather_prepare(st, bs.dense_fwd, xs, ws.filters, false, ws.table, ws.tiled, cand[ci].guard);
+                    ProfScope prof(p, 0, st);
+                    dense_gather_run(st, bs.dense_fwd, ys, ws.tiled, cand[ci].guard);
+                    continue;
+                }
+                const TiledConfig& cfg = bs.tiled_fwd;
+                for (int window = 0; window < tiled_gather_windows(cfg); ++window) {   // one pass unless the bucket is 32
+                    tiled_gather_prepare(st, cfg, xs, ws.filters, false, ws.table, ws.tiled, window, cand[ci].guard);
+                    ProfScope prof(p, 0, st);
+                    tiled_gather_run(st, cfg, ys, ws.tiled, window > 0, cand[ci].guard);
+                }
             }
         }
     } else {
@@ -472,11 +519,17 @@ int run_param_sums(const dau_conv_plan* p, hipStream_t st, const float* x, const
     if (p->algo_bwd == DAU_ALGO_TILED) {
         Candidate cand[2];
         const int ncand = pick_candidates(p, ws.status, 1, cand);
+        const size_t esize = (flags & DAU_FLAG_IO_BF16) ? 2 : 4;
         for (int ci = 0; ci < ncand; ++ci) {
-            const TiledDotConfig& cfg = cand[ci].set->tiled_dot;
-            tiled_dot_prepare(st, cfg, x, dy, ws.filters, ws.table_bare, p->drop_col, p->drop_row, ws.tiled_dot, cand[ci].guard);
-            ProfScope prof(p, 2, st);
-            tiled_dot_run(st, cfg, r4, ws.tiled_dot, cand[ci].guard);
+            const BucketSet& bs = *cand[ci].set;
+            const TiledDotConfig& cfg = bs.tiled_dot;
+            for (int n0 = 0; n0 < s.N; n0 += bs.slab_dot) {                // the sums of the slabs add up in r4
+                tiled_dot_prepare(st, cfg, slab_ptr(x, (size_t)n0 * s.S * s.H * s.W, esize),
+                                  slab_ptr(dy, (size_t)n0 * s.F * s.H * s.W, esize), ws.filters, ws.table_bare, p->drop_col,
+                                  p->drop_row, ws.tiled_dot, cand[ci].guard);
+                ProfScope prof(p, 2, st);
+                tiled_dot_run(st, cfg, r4, ws.tiled_dot, cand[ci].guard, n0 > 0);
+            }
         }
     } else {
         launch_blur_direct(st, x, (long)s.N * s.S, s.H, s.W, ws.filters + 1 * kFilterPlane, kNumK, p->blur_k, ws.xk4);
@@ -528,18 +581,24 @@ int dau_conv_backward(const dau_conv_plan* p, void* stream, const float* x, cons
         if (p->algo_fwd == DAU_ALGO_TILED) {
             Candidate cand[2];
             const int ncand = pick_candidates(p, ws.status, 0, cand);
+            const size_t esize = (flags & DAU_FLAG_IO_BF16) ? 2 : 4;
             for (int ci = 0; ci < ncand; ++ci) {
-                if (cand[ci].set->dense_ok) {
-                    dense_gather_prepare(st, cand[ci].set->dense_dx, dy, ws.filters, true, ws.table_t, ws.tiled_dx, cand[ci].guard);
-                    ProfScope prof(p, 1, st);
-                    dense_gather_run(st, cand[ci].set->dense_dx, dx, ws.tiled_dx, cand[ci].guard);
-                    continue;
-                }
-                const TiledConfig& cfg = cand[ci].set->tiled_dx;
-                for (int window = 0; window < tiled_gather_windows(cfg); ++window) {
-                    tiled_gather_prepare(st, cfg, dy, ws.filters, true, ws.table_t, ws.tiled_dx, window, cand[ci].guard);
-                    ProfScope prof(p, 1, st);
-                    tiled_gather_run(st, cfg, dx, ws.tiled_dx, window > 0, cand[ci].guard);
+                const BucketSet& bs = *cand[ci].set;
+                for (int n0 = 0; n0 < s.N; n0 += bs.slab_gather) {
+                    const float* dys = slab_ptr(dy, (size_t)n0 * s.F * s.H * s.W, esize);
+                    float* dxs = slab_ptr(dx, (size_t)n0 * s.S * s.H * s.W, esize);
+                    if (bs.dense_ok) {
+                        dense_gather_prepare(st, bs.dense_dx, dys, ws.filters, true, ws.table_t, ws.tiled_dx, cand[ci].guard);
+                        ProfScope prof(p, 1, st);
+                        dense_gather_run(st, bs.dense_dx, dxs, ws.tiled_dx, cand[ci].guard);
+                        continue;
+                    }
+                    const TiledConfig& cfg = bs.tiled_dx;
+                    for (int window = 0; window < tiled_gather_windows(cfg); ++window) {
+                        tiled_gather_prepare(st, cfg, dys, ws.filters, true, ws.table_t, ws.tiled_dx, window, cand[ci].guard);
+                        ProfScope prof(p, 1, st);
+                        tiled_gather_run(st, cfg, dxs, ws.tiled_dx, window > 0, cand[ci].guard);
+                    }
                 }
             }
         } else {

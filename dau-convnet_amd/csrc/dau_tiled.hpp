@@ -76,7 +76,8 @@ size_t tiled_dot_workspace_bytes(const TiledDotConfig& cfg);
 void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& cfg, const float* x, const float* dy,
                        const float* filters, const UnitRef* table_bare, int drop_col, int drop_row, void* workspace,
                        const Guard& guard);
-void tiled_dot_run(hipStream_t st, const TiledDotConfig& cfg, float* r4, void* workspace, const Guard& guard);
+// accumulate: add this batch slab's sums to r4 instead of overwriting it
+void tiled_dot_run(hipStream_t st, const TiledDotConfig& cfg, float* r4, void* workspace, const Guard& guard, bool accumulate);
 void tiled_dot_init(const TiledDotConfig& cfg);
 
 }  // namespace dau

@@ -388,8 +388,9 @@ __global__ void dot_params_binned_kernel(const UnitRef* __restrict__ table, int 
 // r4[k][u] = sum over the slabs of partial[slab][k][u]; units g < g_split were written by a pass with slabs0 slabs,
 // the others by a pass with slabs1 (u = (s*G + g)*F + f)
 // zero_from: units g >= zero_from have no partial sums (binned passes give ignored units no slot): their sums are zero
+// accumulate: add to r4 (second and later batch slabs of a call) instead of overwriting it
 __global__ void dot_reduce_kernel(const float* __restrict__ partial, long n, int G, int F, int g_split, int slabs0,
-                                  int slabs1, int zero_from, float* __restrict__ r4, const Guard guard) {
+                                  int slabs1, int zero_from, int accumulate, float* __restrict__ r4, const Guard guard) {
     if (!guard_pass(guard)) return;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int g = (int)((i / F) % G);
@@ -397,7 +398,7 @@ __global__ void dot_reduce_kernel(const float* __restrict__ partial, long n, int
         double s = 0.0;
         if (g < zero_from)
             for (int c = 0; c < slabs; ++c) s += (double)partial[(long)c * n + i];
-        r4[i] = (float)s;
+        r4[i] = accumulate ? (float)((double)r4[i] + s) : (float)s;
     }
 }
 
@@ -949,7 +950,7 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
     }
 }
 
-void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* workspace, const Guard& guard) {
+void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* workspace, const Guard& guard, bool accumulate) {
     const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile, c.rounds);
     const DotLayout l = dot_layout(c, g);
     char* ws = static_cast<char*>(workspace);
@@ -978,7 +979,7 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
     const int rgrid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     const int g_split = g.npass == 2 ? g.pass[1].g_begin : s.G;
     hipLaunchKernelGGL(dot_reduce_kernel, dim3(rgrid), dim3(256), 0, st, a.partial, n, s.G, s.F, g_split,
-                       g.pass[0].chunks, g.pass[g.npass - 1].chunks, binned ? s.G - c.ignore : s.G, r4, guard);
+                       g.pass[0].chunks, g.pass[g.npass - 1].chunks, binned ? s.G - c.ignore : s.G, accumulate ? 1 : 0, r4, guard);
 }
 
 }  // namespace dau

@@ -189,3 +189,30 @@ def test_dynamic_bucket_costs_what_the_offsets_need():
     print("k=9 %.3f ms, k=65 dynamic %.3f ms, k=65 static %.3f ms" % (t9, t65, t65s))
     assert t65 < 1.25 * t9 + 0.3, (t9, t65, t65s)          # the guarded-out static set costs a few empty launches
     assert t65s > 1.5 * t65, (t65, t65s)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16", "bf16-dense"])
+def test_batch_slabs_under_a_workspace_budget(mode, monkeypatch):
+    """With a workspace budget smaller than the staged copy of the whole batch (DAU_WORKSPACE_BUDGET_GB at plan creation; by
+    default only the 512 x 512 configurations get there) every pass runs slab by slab over the batch: y and dx slab-wise,
+    the parameter sums added up over the slabs.  Same results as the oracle on the whole batch, smaller workspace."""
+    from dau_conv import _capi
+    N, S, F, G, H, W, k = 12, 6, 10, 3, 40, 36, 17
+    m = 3.5 if mode == "bf16-dense" else 7.5
+    x, dy, w, mu1, mu2 = _inputs(51, N, S, F, G, H, W, k, m)
+    flags = _capi.FLAG_USE_INTERPOLATION
+    dtype, io_rel, io_floor = torch.float32, 1e-4, 1e-6
+    if mode != "f32":
+        flags |= _capi.FLAG_IO_BF16
+        dtype, io_rel, io_floor = torch.bfloat16, 2e-2, 4e-3
+        x = torch.from_numpy(x).to(torch.bfloat16).float().numpy(); dy = torch.from_numpy(dy).to(torch.bfloat16).float().numpy()
+    if mode == "bf16-dense":
+        flags |= _capi.FLAG_DENSE_BF16
+    whole = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, sigma_hint=0.5, flags=flags)
+    monkeypatch.setenv("DAU_WORKSPACE_BUDGET_GB", "0.0005")
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, sigma_hint=0.5, flags=flags)
+    assert whole.info["batch_slab_gather"] == N and whole.info["batch_slab_dot"] == N
+    assert plan.info["batch_slab_gather"] < N and plan.info["batch_slab_dot"] < N, plan.info
+    assert plan.workspace_bytes(_capi.PASS_BACKWARD) < whole.workspace_bytes(_capi.PASS_BACKWARD)
+    got = _run(plan, x, dy, w, mu1, mu2, dtype=dtype, calls=2)       # second call: hinted bucket, also in slabs
+    _check_all(got, x, dy, w, mu1, mu2, "slabs/" + mode, io_rel=io_rel, io_floor=io_floor)
