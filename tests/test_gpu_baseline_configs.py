@@ -187,8 +187,9 @@ def test_dynamic_bucket_costs_what_the_offsets_need():
     t65s = ms(_capi.Plan(N, S, F, G, H, W, max_kernel_size=65, sigma_hint=0.5,
                          flags=_capi.FLAG_USE_INTERPOLATION | _capi.FLAG_STATIC_BUCKET))
     print("k=9 %.3f ms, k=65 dynamic %.3f ms, k=65 static %.3f ms" % (t9, t65, t65s))
-    assert t65 < 1.25 * t9 + 0.3, (t9, t65, t65s)          # the guarded-out static set costs a few empty launches
-    assert t65s > 1.5 * t65, (t65, t65s)
+    # measured: 0.575 / 0.575 / 1.18 ms.  Generous margins: this is a timing assertion inside a correctness suite
+    assert t65 < 1.5 * t9 + 0.5, (t9, t65, t65s)           # the guarded-out static set costs a few empty launches
+    assert t65s > 1.2 * t65, (t65, t65s)
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16", "bf16-dense"])
