@@ -50,11 +50,21 @@
  * then accumulates, dau_conv_grad_op.cpp:202-205 -- same net result).
  *
  * Offset buckets.  The kernels stage a border of R pixels around every tile, R in
- * {4, 8, 16, 24, 32}.  The reference picks R per call from a blocking amax of mu1/mu2
+ * {4, 8, 16, 18, 20, 24, 32}.  The reference picks R per call from a blocking amax of mu1/mu2
  * (dau_conv_op.cpp:223-253).  Here a plan holds the kernel sets of every R up to the one
  * max_kernel_size allows; a call enqueues the set that covered the previous call's max|mu|
  * (read from the pinned mirror, no sync) plus the largest set, each guarded on the device by
  * THIS call's max|mu|, so exactly one does the work and results never depend on the hint.
+ *
+ * Workspace.  Every pass stages its input before it gathers.  Where the staged copy of the
+ * whole batch would exceed 12 GB (DAU_WORKSPACE_BUDGET_GB in the environment at plan
+ * creation; only 512 x 512 maps get there) the pass runs over the batch in slabs of an even
+ * divisor of N images, and dau_conv_workspace_bytes reports the smaller requirement.
+ *
+ * HIP graphs.  After one ordinary call (which sets the kernels' launch attributes) forward and
+ * backward only enqueue kernels and one 16-byte memset on the caller's stream, so they can be
+ * captured into a graph; the bucket candidates are frozen at capture time, the device-side
+ * guards still pick the kernels the replay's offsets need.
  */
 #ifndef DAU_CONV_H_
 #define DAU_CONV_H_
@@ -130,8 +140,8 @@ typedef struct dau_conv_desc {
     int32_t out_channels;           /* F  (attr num_output)                                       */
     int32_t units_per_channel;      /* G  (number_units_x * number_units_y, incl. ignored units)  */
     int32_t height, width;          /* H, W (output size == input size, dau_conv_op.cpp:185-188)  */
-    int32_t max_kernel_size;        /* attr kernel_size: 9/17/33/49/65 -> largest offset bucket
-                                       4/8/16/24/32                                               */
+    int32_t max_kernel_size;        /* attr kernel_size: 9/17/33/37/41/49/65 -> largest offset
+                                       bucket 4/8/16/18/20/24/32                                  */
     int32_t number_units_ignore;    /* attr number_units_ignore                                   */
     int32_t flags;                  /* DAU_FLAG_*                                                 */
     int32_t algo;                   /* DAU_ALGO_*                                                 */
@@ -144,7 +154,7 @@ typedef struct dau_conv_desc {
 typedef struct dau_conv_plan dau_conv_plan; /* opaque */
 
 typedef struct dau_conv_plan_info {
-    int32_t offset_bucket;     /* largest (static) R in {4,8,16,24,32}                            */
+    int32_t offset_bucket;     /* largest (static) R in {4,8,16,18,20,24,32}                      */
     int32_t blur_support;      /* k of the k x k prefilter                                        */
     int32_t algo_forward;      /* DAU_ALGO_* actually used by dau_conv_forward / the dx pass      */
     int32_t algo_backward;     /* DAU_ALGO_* actually used for the parameter gradients            */
