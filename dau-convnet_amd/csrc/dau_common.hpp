@@ -12,6 +12,62 @@ __device__ __forceinline__ float load_act(const float* base, long idx, bool bf16
     if (!bf16) return base[idx];
     return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(base)[idx] << 16);
 }
+// the stored bits of an activation, untouched (no arithmetic on a value still in flight), and their conversion
+template <bool BF> struct RawAct { typedef float type; };
+template <> struct RawAct<true> { typedef unsigned type; };   // (zero-extended by the load; a 16-bit pair would be packed = arithmetic)
+template <bool BF>
+__device__ __forceinline__ typename RawAct<BF>::type load_raw(const float* base, long idx) {
+    if constexpr (!BF) return base[idx];
+    else return reinterpret_cast<const unsigned short*>(base)[idx];
+}
+__device__ __forceinline__ float act_of(float v) { return v; }
+__device__ __forceinline__ float act_of(unsigned v) { return __uint_as_float(v << 16); }
+template <bool BF>
+__device__ __forceinline__ float load_act_t(const float* base, long idx) {
+    if constexpr (!BF) return base[idx];
+    else return __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(base)[idx] << 16);
+}
+// v where keep, +0 elsewhere, as a bit mask: with a select hipcc moves the load that produced v under a branch on `keep`
+__device__ __forceinline__ float mask_act(float v, bool keep) { return __uint_as_float(__float_as_uint(v) & (keep ? 0xffffffffu : 0u)); }
+// Load phase of the staging kernels: rows_ x cols_ items of one plane split over the nw waves of its wave group, the loads of
+// kLoadBatch items issued back to back before the first of them is stored to LDS.  These kernels are HBM bound, and a wave with
+// one or two loads in flight keeps far fewer bytes in the air than the memory latency needs (Little's law: ~50 KB per CU).
+// ld(r, x) -> value must be BRANCH FREE (clamped address + select): a branch around a load makes hipcc wait for it at the
+// join, one load at a time.  It returns the loaded bits untouched (RawAct / load_raw); st converts and masks them.  Items past the end load item (rows_-1, cols_-1) again and store nothing.  st(r, x, value).
+// A wave per row when the rows are wide, a flat index when they are narrow.
+#ifndef DAU_LOAD_BATCH
+#define DAU_LOAD_BATCH 6
+#endif
+constexpr int kLoadBatch = DAU_LOAD_BATCH;
+template <class V, class Load, class Store>
+__device__ __forceinline__ void load_phase(int rows_, int cols_, int wave, int nw, int lane, Load&& ld, Store&& st) {
+    if (cols_ >= 56) {
+        for (int x0 = 0; x0 < cols_; x0 += 64) {
+            const int x = x0 + lane, xc = x < cols_ ? x : cols_ - 1;
+            for (int r0 = wave; r0 < rows_; r0 += nw * kLoadBatch) {
+                V v[kLoadBatch];
+#pragma unroll
+                for (int u = 0; u < kLoadBatch; ++u) { const int r = r0 + u * nw; v[u] = ld(r < rows_ ? r : rows_ - 1, xc); }
+#pragma unroll
+                for (int u = 0; u < kLoadBatch; ++u) { const int r = r0 + u * nw; if (r < rows_ && x < cols_) st(r, x, v[u]); }
+            }
+        }
+    } else {
+        const int total = rows_ * cols_;
+        for (int t0 = wave * 64 + lane; t0 < total; t0 += nw * 64 * kLoadBatch) {
+            V v[kLoadBatch];
+            int rr[kLoadBatch];
+#pragma unroll
+            for (int u = 0; u < kLoadBatch; ++u) {
+                const int t = t0 + u * nw * 64, tc = t < total ? t : total - 1;
+                rr[u] = tc / cols_;
+                v[u] = ld(rr[u], tc - rr[u] * cols_);
+            }
+#pragma unroll
+            for (int u = 0; u < kLoadBatch; ++u) { const int t = t0 + u * nw * 64; if (t < total) st(rr[u], t - rr[u] * cols_, v[u]); }
+        }
+    }
+}
 __device__ __forceinline__ void store_act(float* base, long idx, float v, bool bf16, bool accumulate) {
     if (!bf16) { base[idx] = accumulate ? base[idx] + v : v; return; }
     unsigned short* p = reinterpret_cast<unsigned short*>(base) + idx;

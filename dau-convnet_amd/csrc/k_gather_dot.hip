@@ -49,6 +49,9 @@ constexpr int kRW = 8;           // region of positions q handled per item: kRW 
 #define DAU_DOT_WAVES 16
 #endif
 constexpr int kDWaves = DAU_DOT_WAVES;
+#ifndef DAU_DOT_PRIO
+#define DAU_DOT_PRIO 0          // timing experiment: 1 = s_setprio 2 around the MFMA burst, 2 = 1 / 3 / 0 for interpolation / MFMA / reads
+#endif
 constexpr int kParamDwords = 8;  // per lane per (s, g-pair): b00,b01,b10,b11, base, pad x3
 
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -186,13 +189,33 @@ __global__ void __launch_bounds__(256) pack_error_kernel(const float* __restrict
     const bool rowin = y >= 0 && y < H && !(drop_row && y == H - 1);
     if (rowin && cw > 0) {
         // flat over (r = fl*2 + image, x): narrow maps keep all lanes busy (a 7-pixel row per wave instruction did not)
-        for (int t = threadIdx.x; t < 64 * cw; t += blockDim.x) {
-            const int r = t / cw, x = t - r * cw;
-            const int f = fb * kDF + (r >> 1), n = 2 * np + (r & 1);
-            const bool ok = f < F && n < N;
-            const long src = (((long)(ok ? n : 0) * F + (ok ? f : 0)) * H + y) * W + xa0;
-            lds[r * wp + x] = ok ? load_act(dy, src + x, bf16 != 0) : 0.0f;
-        }
+        // (the loads of kLoadBatch items go out before the first is stored, branch free: see load_phase in dau_common.hpp)
+        auto fill = [&](auto bfc) {
+            constexpr bool BF = decltype(bfc)::value;
+            const int total = 64 * cw;
+            for (int t0 = threadIdx.x; t0 < total; t0 += blockDim.x * kLoadBatch) {
+                typename RawAct<BF>::type v[kLoadBatch];
+                int rr[kLoadBatch];
+                bool okk[kLoadBatch];
+#pragma unroll
+                for (int u = 0; u < kLoadBatch; ++u) {
+                    const int t = t0 + u * blockDim.x, tc = t < total ? t : total - 1;
+                    const int r = tc / cw, x = tc - r * cw;
+                    rr[u] = r;
+                    const int f = fb * kDF + (r >> 1), n = 2 * np + (r & 1);
+                    const bool ok = f < F && n < N;
+                    const long src = (((long)(ok ? n : 0) * F + (ok ? f : 0)) * H + y) * W + xa0;
+                    v[u] = load_raw<BF>(dy, src + x);
+                    okk[u] = ok;
+                }
+#pragma unroll
+                for (int u = 0; u < kLoadBatch; ++u) {
+                    const int t = t0 + u * blockDim.x;
+                    if (t < total) lds[rr[u] * wp + (t - rr[u] * cw)] = mask_act(act_of(v[u]), okk[u]);
+                }
+            }
+        };
+        if (bf16) fill(std::true_type{}); else fill(std::false_type{});
     }
     __syncthreads();
     float* out = ep + ((((size_t)np * nfb + fb) * EY + Y) * EX + X0) * (kDF * 2);
@@ -269,12 +292,24 @@ __global__ void __launch_bounds__(512) blur4_pack_kernel(const Blur4Args a) {
             for (int t = wave * 64 + lane; t < rows_ * cols_; t += nw * 64) { const int r = t / cols_; body(r, t - r * cols_); }
         }
     };
-    for_each(lh, lw, [&](int r, int xl) {
-        const int yy = oy0 - kr + r, xx = ox0 - kr + xl;
-        f2 v = {0.0f, 0.0f};
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) { v.x = m0 * load_act(a.in, p0 + yy * W + xx, bf16); v.y = m1 * load_act(a.in, p1 + yy * W + xx, bf16); }
-        A[r * lw + xl] = v;
-    });
+    // raw window -> LDS, the loads of a batch in flight together (load_phase, dau_common.hpp)
+    auto fill = [&](auto bfc) {
+        constexpr bool BF = decltype(bfc)::value;
+        struct Raw2 { typename RawAct<BF>::type v0, v1; };
+        load_phase<Raw2>(lh, lw, wave, nw, lane,
+            [&](int r, int xl) {
+                const int yy = oy0 - kr + r, xx = ox0 - kr + xl;
+                const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                const long off = in ? (long)yy * W + xx : 0;            // outside the image: element 0 (valid), discarded
+                return Raw2{load_raw<BF>(a.in, p0 + off), load_raw<BF>(a.in, p1 + off)};
+            },
+            [&](int r, int xl, Raw2 v) {
+                const int yy = oy0 - kr + r, xx = ox0 - kr + xl;
+                const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                A[r * lw + xl] = f2{mask_act(m0 * act_of(v.v0), in), mask_act(m1 * act_of(v.v1), in)};
+            });
+    };
+    if (bf16) fill(std::true_type{}); else fill(std::false_type{});
     __syncthreads();
     for_each(lh, ow, [&](int r, int x) {
         const int yy = oy0 - kr + r;
@@ -742,6 +777,9 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                  : "v"(E0[0]), "v"(E0[1]), "v"(E0[2]), "v"(E0[3]), "v"(L0[0]), "v"(L0[1]), "v"(L0[2]), "v"(L0[3]),   \
                    "v"(E1[0]), "v"(E1[1]), "v"(E1[2]), "v"(E1[3]), "v"(L1[0]), "v"(L1[1]), "v"(L1[2]), "v"(L1[3]),   \
                    "v"(A0), "v"(A1), "v"(A2), "v"(A3), "v"(B0), "v"(B1), "v"(B2), "v"(B3))
+#if DAU_DOT_PRIO == 2
+                    __builtin_amdgcn_s_setprio(1);
+#endif
                     {
                         // flatten [GS][GP] (GS*GP == 4 in every instantiation) into chain order
                         static_assert(GS * GP == 4, "four interleaved chains");
@@ -761,6 +799,9 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                         if (!BINNED && si == 0 && two) x_wait<kXSlots - 1 + kRounds4>();
                         else x_wait<kXSlots - 1>();
                     }
+#if DAU_DOT_PRIO
+                    __builtin_amdgcn_s_setprio(DAU_DOT_PRIO == 2 ? 3 : 2);
+#endif
 #pragma unroll
                     for (int p = 0; p < GS; ++p) {
 #pragma unroll
@@ -770,6 +811,9 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                             acc[si][gp][1] = mfma_bcast(xr[j / 2].y, et[p][gp].y, acc[si][gp][1], abid);
                         }
                     }
+#if DAU_DOT_PRIO
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                     // the row pair is consumed: refill its slot with the same rows of the next sweep
                     if ((j % 2 == 1 || j + 1 == kRH) && gq + 1 == kGroups) x_load(xr[j / 2], xlane, xnext_sweep + (j / 2) * 2 * xpitch, 0);

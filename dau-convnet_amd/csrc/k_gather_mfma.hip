@@ -202,7 +202,7 @@ struct BlurPackArgs {
 
 // K: compile-time prefilter support (taps live in SGPRs, tap loops unrolled); K = 0: any support, taps re-read per use
 template <int K>
-__global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) blur_pack_kernel(const BlurPackArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (!guard_pass(a.guard)) return;
     const int C = a.C, H = a.H, W = a.W, R = a.R, k = K ? K : a.k;
@@ -228,6 +228,8 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
     const int lw = bw + 2 * kr, lh = (ya1 - ya0) + 2 * kr;
     f2* A = reinterpret_cast<f2*>(lds + (size_t)sub * a.lds_plane_floats);   // raw window, zero outside the image   [lh][lw]
     f2* B = A + (size_t)lh * lw;                  // after the horizontal pass            [lh][bw]
+    const int tp = a.band_rows | 1;
+    f2* T = B + (size_t)lh * bw;                  // strip columns of this band, column-major  [strip_cols][tp]
     const float* gxp = a.taps + (a.mirrored ? kTapGXR : kTapGX) * kTapPitch;
     const float* gyp = a.taps + (a.mirrored ? kTapGYR : kTapGY) * kTapPitch;
     float gxr[K ? K : 1], gyr[K ? K : 1];
@@ -243,20 +245,33 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
     const float m1 = n1 < a.N ? 1.0f : 0.0f;      // odd batch: the second image of the last pair is zero
     // rows x cols of work for this plane's waves: a wave per row when the rows are wide, a flat index when they are narrow
     // (a 7-pixel row would leave most of a wave idle)
+    // (nor a 72-position row: its second wave instruction would run with 8 of 64 lanes)
     auto for_each = [&](int rows_, int cols_, auto&& body) {
-        if (cols_ >= 56) {
+        if (cols_ >= 56 && (cols_ % 64 == 0 || cols_ % 64 >= 48)) {
             for (int r = wave; r < rows_; r += nw)
                 for (int x = lane; x < cols_; x += 64) body(r, x);
         } else {
             for (int t = wave * 64 + lane; t < rows_ * cols_; t += nw * 64) { const int r = t / cols_; body(r, t - r * cols_); }
         }
     };
-    for_each(lh, lw, [&](int r, int xl) {
-        const int yy = ya0 - kr + r, xx = xa0 - kr + xl;
-        f2 v = {0.0f, 0.0f};
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) { v.x = load_act(a.in, p0 + yy * W + xx, bf16); v.y = m1 * load_act(a.in, p1 + yy * W + xx, bf16); }
-        A[r * lw + xl] = v;
-    });
+    // raw window -> LDS, the loads of a batch in flight together (load_phase, dau_common.hpp)
+    auto fill = [&](auto bfc) {
+        constexpr bool BF = decltype(bfc)::value;
+        struct Raw2 { typename RawAct<BF>::type v0, v1; };
+        load_phase<Raw2>(lh, lw, wave, nw, lane,
+            [&](int r, int xl) {
+                const int yy = ya0 - kr + r, xx = xa0 - kr + xl;
+                const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                const long off = in ? (long)yy * W + xx : 0;            // outside the image: element 0 (valid), discarded
+                return Raw2{load_raw<BF>(a.in, p0 + off), load_raw<BF>(a.in, p1 + off)};
+            },
+            [&](int r, int xl, Raw2 v) {
+                const int yy = ya0 - kr + r, xx = xa0 - kr + xl;
+                const bool in = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                A[r * lw + xl] = f2{mask_act(act_of(v.v0), in), mask_act(m1 * act_of(v.v1), in)};
+            });
+    };
+    if (bf16) fill(std::true_type{}); else fill(std::false_type{});
     __syncthreads();
     for_each(lh, bw, [&](int r, int x) {
         const int yy = ya0 - kr + r;
@@ -280,9 +295,19 @@ __global__ void __launch_bounds__(512) blur_pack_kernel(const BlurPackArgs a) {
         }
         out[row * a.pitch + col] = acc;
         // columns pw .. pw+2R are stored a second time column-major: the edge-column tile of the gather reads a
-        // vertical run of positions, which is bank-conflict free only in this orientation
-        if (a.strip_cols > 0 && col >= a.pw && col < a.pw + a.strip_cols) strip[(col - a.pw) * a.rows + row] = acc;
+        // vertical run of positions, which is bank-conflict free only in this orientation.  They are collected in LDS
+        // and written as runs of rows below (straight from here they were nine scattered 8-byte writes per row, three
+        // times the write transactions of the row itself)
+        if (a.strip_cols > 0 && col >= a.pw && col < a.pw + a.strip_cols) T[(col - a.pw) * tp + brow] = acc;
     });
+    if (a.strip_cols > 0) {
+        __syncthreads();
+        const int nr = active ? row1 - row0 : 0;
+        for (int t = wave * 64 + lane; t < a.strip_cols * nr; t += nw * 64) {
+            const int cidx = t / nr, r = t - cidx * nr;
+            strip[(size_t)cidx * a.rows + row0 + r] = T[cidx * tp + r];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -813,7 +838,8 @@ auto blur_pack_for(int blur_k) {
 size_t blur_pack_lds_bytes(const Geometry& g, int k, int band_rows = 0) {
     const int rows = band_rows > 0 && band_rows < g.rows ? band_rows : g.rows;
     const size_t wh = rows < g.H ? rows : g.H, ww = g.cols < g.W ? g.cols : g.W;
-    return ((wh + k - 1) * (ww + k - 1) + (wh + k - 1) * ww) * 8;
+    const size_t strip = g.edge ? (size_t)(2 * g.Rt + 1) * (rows | 1) : 0;      // column-major copy of the strip columns
+    return ((wh + k - 1) * (ww + k - 1) + (wh + k - 1) * ww + strip) * 8;
 }
 
 // planes that need more than ~40 KiB of LDS are staged in two (or more) row bands
