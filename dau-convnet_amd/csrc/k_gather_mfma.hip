@@ -99,6 +99,11 @@ const Variant kVariants[] = {
                                         //     73.7 / 69.4 TF against 71.1 / 67.8 for the three stacked images of row 12)
     {4, 4, 40, 0, 2, 2, 13312, 4, 2},   // 19: two stacked 25..31 pixel images (tuning alternative, DAU_GATHER_VARIANT=19: no gain)
     {7, 7, 72, 1, 2, 1, 0, 4, 2, 3},    // 20: row 0 with three plane buffers and lagged partner waves (DAU_GATHER_VARIANT=20)
+    {4, 4, 40, 0, 1, 1, 0, 12, 0},      // 21: one 25..31 pixel image, twelve channels on its plane: a plane is fetched from L2 a
+                                        //     third as often as with four (27x27, 96 -> 256 channels, 64 images: dx 0.78 -> 0.54 ms;
+                                        //     28x28 at 512 channels: 11.0 / 11.6 -> 10.5 / 10.9 ms).  Sixteen channels = 1024
+                                        //     threads spill (20x slower): not instantiated.
+    {4, 4, 104, 0, 1, 1, 0, 12, 0},     // 22: 31 pixel patches, R <= 28, twelve channels (512x512, bucket 18: 250 -> 242 ms per pass)
 };
 
 // one (channel block, input channel) slice of the packed unit table: [G slots][fb channels][8 dwords]; window passes
@@ -159,6 +164,8 @@ Geometry make_geometry(int H, int W, int R, int G, int N, int Cout, int only = -
         double cost = (double)groups * (v.sk * (v.tx * v.ty + edge_tiles + 0.02 * rows * v.pitch / 8.0 * (4.0 / v.fb)) + 12.0 * (4.0 / v.fb));
         // a grid that ends with a nearly empty round of workgroups wastes the chip: price the rounds, not the blocks
         cost *= (double)((blocks + 255) / 256 * 256) / (double)blocks;
+        // channel slots of the last, partly filled channel block
+        cost *= (double)((Cout + v.fb - 1) / v.fb * v.fb) / (double)Cout;
         if (v.tuning && only < 0) cost = 0.0;                // explicitly requested
         if (g.variant >= 0 && cost >= best) continue;
         best = cost;
@@ -825,6 +832,8 @@ void dispatch_variant(int variant, hipStream_t st, const GatherArgs* a, int grid
         case 18: launch_variant<GatherTraits<4, 4, 40, false, 1, 1, 0, 8>>(st, a, grid, lds); break;
         case 19: launch_variant<GatherTraits<4, 4, 40, false, 2, 2, 13312, 4>>(st, a, grid, lds); break;
         case 20: launch_variant<GatherTraits<7, 7, 72, true, 2, 1, 0, 4, 3>>(st, a, grid, lds); break;
+        case 21: launch_variant<GatherTraits<4, 4, 40, false, 1, 1, 0, 12>>(st, a, grid, lds); break;
+        case 22: launch_variant<GatherTraits<4, 4, 104, false, 1, 1, 0, 12>>(st, a, grid, lds); break;
         default: break;
     }
 }

@@ -267,6 +267,10 @@ def test_seeded_shapes_against_c_oracle(shape, algo):
     dict(N=2, W=56, H=56, S=3, F=9, G=3, k=9, m=3, variant=20, stack=1, patch=56),
     dict(N=2, W=80, H=56, S=1, F=8, G=6, k=9, m=3, variant=20, stack=1, patch=56),
     dict(N=2, W=56, H=56, S=2, F=4, G=9, k=9, m=3, variant=20, stack=1, patch=56),
+    # twelve output channels per workgroup on one 25..31 pixel image (row 21): whole and partial channel blocks
+    dict(N=3, W=27, H=27, S=5, F=24, G=4, k=9, m=3, variant=21, stack=1, patch=32),
+    dict(N=4, W=28, H=30, S=3, F=17, G=3, k=9, m=3, variant=21, stack=1, patch=32),
+    dict(N=2, W=64, H=40, S=4, F=26, G=5, k=49, m=23.5, variant=22, stack=1, patch=32),  # twelve channels, 31 pixel patches
 ])
 def test_stacked_gather_variants(shape, monkeypatch):
     from dau_conv import _capi

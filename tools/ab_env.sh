@@ -3,7 +3,7 @@
 R=2
 for r in $(seq $R); do
   for E in "$@"; do
-    env $E timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | \
+    env $E timeout -k 10 300 python bench.py $AB_ARGS ${AB_STEPS:---steps 10 --warmup 3} --no-cpu-baseline 2>/dev/null | \
       python -c "import sys,json; d=json.loads(sys.stdin.read()); print('[$E]', d['ms_per_step'], {k:v['avg_ms'] for k,v in d['roofline']['kernels'].items()})"
   done
 done
