@@ -448,6 +448,7 @@ int dau_conv_plan_get_info(const dau_conv_plan* plan, dau_conv_plan_info* info) 
     info->gather_dense_bf16 = plan->sets[0].dense_ok ? 1 : 0;
     info->batch_slab_gather = plan->top().slab_gather;
     info->batch_slab_dot = plan->top().slab_dot;
+    info->dot_region = plan->top().dot_ok ? plan->top().tiled_dot.region_cols * 100 + plan->top().tiled_dot.region_rows : 0;
     return DAU_OK;
 }
 

@@ -64,6 +64,8 @@ struct TiledDotConfig {
     int windows;      // offset windows of radius 8: 1 for R <= 8, 4 for R = 16, 9 for R = 24, 16 for R = 32; with more than
                       // one window the units are binned by window on the device and a window pass visits only its own
     bool as1, one_tile;   // tuning choices read from the environment at plan creation
+    bool rw8;             // DAU_DOT_RW=8 at plan creation: 8-column regions only
+    int region_cols, region_rows;   // positions per (item, input channel) sweep: 8 x 8, 8 x 7, 14 x 4 (or 8 x 4 in bucket 18)
     int rounds;           // DAU_DOT_ROUNDS at plan creation: workgroups per CU the chunking aims at (0: default)
     bool bf16;            // x and dy are bfloat16
     int ignore;           // number_units_ignore: binned window passes give those units no slot

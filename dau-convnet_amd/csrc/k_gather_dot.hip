@@ -28,6 +28,7 @@
 //  Tuning knobs (timing experiments only): -DDAU_DOT_WAVES=8, DAU_DOT_NBUF=1, DAU_DOT_AS1, DAU_DOT_DEBUG.
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "dau_tiled.hpp"
 
@@ -44,7 +45,8 @@ namespace {
 
 constexpr int kDF = 32;        // output channels per workgroup (half a wave; the two halves are two units g)
 constexpr int kRW = 8;           // region of positions q handled per item: kRW columns x RH rows (RH = 8, or 7 for heights
-                                 // such as 7, 14, 28 that waste fewer rows that way)
+                                 // such as 7, 14, 28 that waste fewer rows that way); bucket 4 also has 14 x 4 regions
+                                 // (DotGeometry::RW) for widths such as 27 and 28 that pad to 32 in steps of 8
 #ifndef DAU_DOT_WAVES
 #define DAU_DOT_WAVES 16
 #endif
@@ -57,7 +59,8 @@ constexpr int kParamDwords = 8;  // per lane per (s, g-pair): b00,b01,b10,b11, b
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct DotGeometry {
-    int RH;                     // rows per region: 8 or 7
+    int RW;                     // columns per region: 8, or 14 (with RH = 4; bucket 4, unit blocks of four only)
+    int RH;                     // rows per region: 8 or 7 (4 with RW = 14 and in the wide-window form of bucket 18)
     int epitch, erows;          // LDS error tile (positions)
     int rx, ry;                 // regions per image
     int EX, EY;                 // staged error plane (positions): regions*8 + 2R + 1
@@ -81,7 +84,7 @@ struct DotGeometry {
 };
 
 // as1 / one_tile: tuning choices fixed at plan creation (TiledDotConfig), so that every later call sees the same layout
-DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one_tile = false, int rounds = 0) {
+DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one_tile = false, int rounds = 0, bool rw8 = false) {
     DotGeometry g{};
     // Bucket 18 (offsets within +-18: BASELINE config 4 has +-17): 2 x 2 windows of radius 9 over regions of 4 x 8
     // positions (a 23 x 27 tile fills the LDS like the 25 x 25 one) instead of 3 x 3 windows of radius 8 over 8 x 8
@@ -92,16 +95,28 @@ DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one
     g.Rp = g.nsub1 * g.Rt;
     R = g.Rp;
     const bool binned = g.nsub1 > 1;
-    g.epitch = kRW + 2 * g.Rt + 1;
     // rows per region: 7 when that pads the height less (7, 14, 21, 27, 28, ...)
+    g.RW = kRW;
     g.RH = wide ? 4 : (((sh.H + 6) / 7) * 7 < ((sh.H + 7) / 8) * 8 ? 7 : 8);
+    {
+        // 14 x 4 regions (same 56 positions as 8 x 7; a 13 x 23 tile, two of them fit the LDS) where they pad the map less:
+        // 27 and 28 pixel maps become 28 x 28 instead of 28 x 32 positions.  Bucket 4 only (a bucket 8 tile would not fit),
+        // and only when every pass has two unit pairs per wave (the interpolation block is written for four chains =
+        // two positions x two pairs; one pair per wave takes four positions, which does not divide 14)
+        const long area8 = (long)((sh.W + kRW - 1) / kRW * kRW) * ((sh.H + g.RH - 1) / g.RH * g.RH);
+        const long area14 = (long)((sh.W + 13) / 14 * 14) * ((sh.H + 3) / 4 * 4);
+        const int rem = sh.G % 4;
+        const bool pairs_only = sh.G >= 3 && (rem == 0 || rem == 3);
+        if (g.Rt == 4 && !binned && !as1 && !one_tile && pairs_only && !rw8 && area14 < area8) { g.RW = 14; g.RH = 4; }
+    }
+    g.epitch = g.RW + 2 * g.Rt + 1;
     g.erows = g.RH + 2 * g.Rt + 1;
-    g.rx = (sh.W + kRW - 1) / kRW;
+    g.rx = (sh.W + g.RW - 1) / g.RW;
     g.ry = (sh.H + g.RH - 1) / g.RH;
-    g.EX = g.rx * kRW + 2 * R + 1;
+    g.EX = g.rx * g.RW + 2 * R + 1;
     g.EY = g.ry * g.RH + 2 * R + 1;
     g.Hp = g.ry * g.RH;
-    g.Wp = g.rx * kRW;
+    g.Wp = g.rx * g.RW;
     g.nfb = (sh.F + kDF - 1) / kDF;
     {
         const int full4 = sh.G / 4, rem = sh.G % 4;
@@ -501,10 +516,13 @@ __device__ __forceinline__ f4 mfma_bcast(float a, float b, f4 c, int abid) {
 // row too many, which is never used; the buffer has a spare row at its end)
 // BINNED: window pass over compacted unit slots (dot_params_binned_kernel): a lane's unit index comes with its
 // parameters, input channels whose slots are all empty are skipped by the wave, and a workgroup without any unit leaves.
-template <int GP, int AS, int RH, bool BINNED = false>
+// RW: columns per region (8, or 14 with RH = 4); the Xk ring has one slot per 16 positions of the region in row-major order
+template <int GP, int AS, int RH, bool BINNED = false, int RW = 8>
 __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) gather_dot_kernel(const DotArgs a) {
     constexpr int kRH = RH;
-    constexpr int kXSlots = (RH + 1) / 2;
+    constexpr int kRW = RW;                       // (shadows the namespace constant)
+    constexpr int kXSlots = RW == 8 ? (RH + 1) / 2 : (RH * RW + 15) / 16;
+    static_assert(RW == 8 || (RW % 2 == 0 && !BINNED), "region width");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (!guard_pass(a.guard)) return;
     const int lane = threadIdx.x & 63;
@@ -634,6 +652,20 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     // (and all of the time with one unit pair per wave).  The address is a wave-uniform base (SGPR pair) + one VGPR.
     const size_t xpitch = (size_t)a.Wp * 32;
     const unsigned xlane = (unsigned)((lane >> 5) * xpitch + (lane & 31) * 8);
+    // RW != 8: a slot's 16 positions are not two whole rows; lane 4b+i of slot t holds kind i of the region's position
+    // 16t+b (row-major), clamped to the region's last position
+    unsigned xoff[kXSlots];
+#pragma unroll
+    for (int t = 0; t < kXSlots; ++t) {
+        int P = 16 * t + (lane >> 2);
+        P = P < kRH * kRW ? P : kRH * kRW - 1;
+        xoff[t] = RW == 8 ? 0u : (unsigned)((P / kRW) * xpitch + (P % kRW) * 32 + (lane & 3) * 8);
+    }
+    // slot t of the sweep that starts at `base`
+    auto x_fetch = [&](f2& dst, const char* base, int t) {
+        if constexpr (RW == 8) x_load(dst, xlane, base + 2 * t * xpitch, 0);
+        else x_load(dst, xoff[t], base, 0);
+    };
     auto sweep_ptr = [&](int item, int s) -> const char* {
         const int np_ = item / regions, reg_ = item % regions;
         const int ry_ = reg_ / a.rx, rx_ = reg_ % a.rx;
@@ -654,7 +686,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
         if (!wave_idle) {
             const char* x0 = sweep_ptr(item0, s_base + first_act);
 #pragma unroll
-            for (int i = 0; i < kXSlots; ++i) x_load(xr[i], xlane, x0 + 2 * i * xpitch, 0);
+            for (int i = 0; i < kXSlots; ++i) x_fetch(xr[i], x0, i);
         }
     }
     for (int item = item0; item < item1; ++item) {
@@ -712,7 +744,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
 #pragma unroll
                 for (int gq = 0; gq < kRW / GS; ++gq) {
                     constexpr int kGroups = kRW / GS;
-                    const int par = gq & 1;
+                    const int par = (j * kGroups + gq) & 1;   // running group parity (seven groups per row in the 14-column form)
                     // Prefetch the following group's error columns into the other buffer.  That buffer's LAST column is still
                     // needed (as the left neighbour) by this group's first position, so it is requested only after the
                     // interpolation blocks; the others go out now.
@@ -794,8 +826,10 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                     __builtin_amdgcn_sched_barrier(0);
                     // the other buffer's last column (left neighbour of this group's first position) is now consumed
                     { DAU_PREFETCH_COL(GS - 1) }
-                    // Xk of this row pair: its slot is the oldest of the ring
-                    if (j % 2 == 0 && gq == 0) {
+                    // Xk of this group's positions: when the group opens a new slot (16 positions), that slot is the oldest of
+                    // the ring
+                    const int pos0 = j * kRW + GS * gq;                   // first position of the group, row-major in the region
+                    if (RW == 8 ? (j % 2 == 0 && gq == 0) : (pos0 % 16 == 0)) {
                         if (!BINNED && si == 0 && two) x_wait<kXSlots - 1 + kRounds4>();
                         else x_wait<kXSlots - 1>();
                     }
@@ -806,17 +840,17 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                     for (int p = 0; p < GS; ++p) {
 #pragma unroll
                         for (int gp = 0; gp < GP; ++gp) {
-                            const int abid = (j & 1) * kRW + GS * gq + p;     // position within the slot's 16
-                            acc[si][gp][0] = mfma_bcast(xr[j / 2].x, et[p][gp].x, acc[si][gp][0], abid);
-                            acc[si][gp][1] = mfma_bcast(xr[j / 2].y, et[p][gp].y, acc[si][gp][1], abid);
+                            const int abid = (pos0 + p) % 16, slot = (pos0 + p) / 16;     // position within the slot's 16
+                            acc[si][gp][0] = mfma_bcast(xr[slot].x, et[p][gp].x, acc[si][gp][0], abid);
+                            acc[si][gp][1] = mfma_bcast(xr[slot].y, et[p][gp].y, acc[si][gp][1], abid);
                         }
                     }
 #if DAU_DOT_PRIO
                     __builtin_amdgcn_s_setprio(0);
 #endif
                     __builtin_amdgcn_sched_barrier(0);
-                    // the row pair is consumed: refill its slot with the same rows of the next sweep
-                    if ((j % 2 == 1 || j + 1 == kRH) && gq + 1 == kGroups) x_load(xr[j / 2], xlane, xnext_sweep + (j / 2) * 2 * xpitch, 0);
+                    // the slot is consumed: refill it with the same positions of the next sweep
+                    if ((pos0 + GS) % 16 == 0 || pos0 + GS == kRH * kRW) x_fetch(xr[pos0 / 16], xnext_sweep, pos0 / 16);
                     lgkm_wait0();   // the prefetched group has landed
                 }
                 // next row: tile rows shift down by one
@@ -882,14 +916,19 @@ void blur4_plan(int k, int Hp, int Wp, int* wy, int* wx, size_t* lds) {
 }
 
 // a == nullptr: raise the kernel's dynamic-LDS limit (once per plan and device, tiled_dot_init); else launch
-template <int GP, int AS, int RH, bool BINNED = false>
+template <int GP, int AS, int RH, bool BINNED = false, int RW = 8>
 void launch_dot(hipStream_t st, const DotArgs* a, int grid, size_t lds) {
-    auto kern = gather_dot_kernel<GP, AS, RH, BINNED>;
+    auto kern = gather_dot_kernel<GP, AS, RH, BINNED, RW>;
     if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kDWaves * 64), lds, st, *a);
 }
 
-void dispatch_dot(bool binned, int RH, int GP, int AS, hipStream_t st, const DotArgs* a, int grid, size_t lds) {
+void dispatch_dot(bool binned, int RW, int RH, int GP, int AS, hipStream_t st, const DotArgs* a, int grid, size_t lds) {
+    if (RW == 14) {                                  // 14 x 4 regions: unit blocks of four only (make_dot_geometry)
+        if (AS == 2) launch_dot<2, 2, 4, false, 14>(st, a, grid, lds);
+        else launch_dot<2, 1, 4, false, 14>(st, a, grid, lds);
+        return;
+    }
     if (binned) {
         if (RH == 8) launch_dot<1, 4, 8, true>(st, a, grid, lds);
         else if (RH == 4) launch_dot<1, 4, 4, true>(st, a, grid, lds);
@@ -916,10 +955,11 @@ bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, int igno
     const bool as1 = getenv("DAU_DOT_AS1") != nullptr;
     const bool one_tile = getenv("DAU_DOT_NBUF") && atoi(getenv("DAU_DOT_NBUF")) == 1;
     const int rounds = getenv("DAU_DOT_ROUNDS") ? atoi(getenv("DAU_DOT_ROUNDS")) : 0;
-    const DotGeometry g = make_dot_geometry(sh, R, as1, one_tile, rounds);
+    const bool rw8 = getenv("DAU_DOT_RW") && atoi(getenv("DAU_DOT_RW")) == 8;      // 8-column regions only (A/B of the 14 x 4 form)
+    const DotGeometry g = make_dot_geometry(sh, R, as1, one_tile, rounds, rw8);
     if (g.nbuf * g.tile_bytes + 16 > 160 * 1024) return false;
     // immediates of the unrolled column walk must fit 16 bits
-    if ((size_t)g.epitch * kDF * 8 + (kRW + 1) * kDF * 8 > 65535) return false;
+    if ((size_t)g.epitch * kDF * 8 + (g.RW + 1) * kDF * 8 > 65535) return false;
     {
         int wy, wx; size_t blur_lds;
         blur4_plan(blur_k, g.Hp, g.Wp, &wy, &wx, &blur_lds);
@@ -928,25 +968,25 @@ bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, int igno
     TiledDotConfig c{};
     c.sh = sh; c.R = R; c.blur_k = blur_k; c.NP = (sh.N + 1) / 2; c.variant = g.npass; c.windows = g.nsub1 * g.nsub1;
     c.bf16 = bf16; c.ignore = ignore;
-    c.as1 = as1; c.one_tile = one_tile; c.rounds = rounds; c.debug = getenv("DAU_DOT_DEBUG") ? atoi(getenv("DAU_DOT_DEBUG")) : 0;
+    c.as1 = as1; c.one_tile = one_tile; c.rounds = rounds; c.rw8 = rw8; c.region_cols = g.RW; c.region_rows = g.RH; c.debug = getenv("DAU_DOT_DEBUG") ? atoi(getenv("DAU_DOT_DEBUG")) : 0;
     *cfg = c;
     return true;
 }
 
 size_t tiled_dot_workspace_bytes(const TiledDotConfig& c) {
-    return dot_layout(c, make_dot_geometry(c.sh, c.R, c.as1, c.one_tile, c.rounds)).total;
+    return dot_layout(c, make_dot_geometry(c.sh, c.R, c.as1, c.one_tile, c.rounds, c.rw8)).total;
 }
 
 void tiled_dot_init(const TiledDotConfig& c) {
-    const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile, c.rounds);
-    for (int i = 0; i < g.npass; ++i) dispatch_dot(g.nsub1 > 1, g.RH, g.pass[i].GP, g.pass[i].AS, nullptr, nullptr, 0, 0);
+    const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile, c.rounds, c.rw8);
+    for (int i = 0; i < g.npass; ++i) dispatch_dot(g.nsub1 > 1, g.RW, g.RH, g.pass[i].GP, g.pass[i].AS, nullptr, nullptr, 0, 0);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pack_error_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blur4_pack_for(c.blur_k)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, const float* dy, const float* filters,
                        const UnitRef* table_bare, int drop_col, int drop_row, void* workspace, const Guard& guard) {
-    const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile, c.rounds);
+    const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile, c.rounds, c.rw8);
     const DotLayout l = dot_layout(c, g);
     char* ws = static_cast<char*>(workspace);
     const Shape& s = c.sh;
@@ -995,7 +1035,7 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
 }
 
 void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* workspace, const Guard& guard, bool accumulate) {
-    const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile, c.rounds);
+    const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile, c.rounds, c.rw8);
     const DotLayout l = dot_layout(c, g);
     char* ws = static_cast<char*>(workspace);
     const Shape& s = c.sh;
@@ -1017,7 +1057,7 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
         a.params = reinterpret_cast<const float*>(ws + l.params_off + ps.params_off);
         a.g_begin = ps.g_begin; a.nsb = ps.nsb; a.ngb = ps.ngb; a.chunks = ps.chunks;
         const int grid = ps.chunks * g.nsub1 * g.nsub1 * g.nfb * ps.ngb * ps.nsb;
-        dispatch_dot(binned, g.RH, ps.GP, ps.AS, st, &a, grid, lds);
+        dispatch_dot(binned, g.RW, g.RH, ps.GP, ps.AS, st, &a, grid, lds);
     }
     const long n = (long)kNumK * s.S * s.G * s.F;
     const int rgrid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);

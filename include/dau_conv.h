@@ -169,6 +169,8 @@ typedef struct dau_conv_plan_info {
     int32_t batch_slab_gather; /* images staged and gathered at a time by the y / dx passes and   */
     int32_t batch_slab_dot;    /* by the parameter-gradient pass of the static bucket (= batch
                                   unless the staged copy would exceed the workspace budget)      */
+    int32_t dot_region;        /* tiled gather-dot of the static bucket: 100 * columns + rows of the
+                                  positions one sweep covers (808, 807, 1404, 804; 0: direct)     */
 } dau_conv_plan_info;
 
 DAU_API int dau_conv_abi_version(void);

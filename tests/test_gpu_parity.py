@@ -296,6 +296,45 @@ def test_stacked_gather_variants(shape, monkeypatch):
         assert_parity(t.cpu().numpy(), want[key], key)
 
 
+@pytest.mark.parametrize("shape", [
+    # gather-dot over 14 x 4 regions (maps whose width pads less in steps of 14 than of 8; unit counts that give every wave
+    # two unit pairs): whole and partial regions, odd batches, partial channel blocks, both passes' layouts (AS 2 and 1)
+    dict(N=3, W=28, H=28, S=5, F=40, G=4, region=1404),
+    dict(N=4, W=27, H=27, S=33, F=20, G=4, region=1404),
+    dict(N=2, W=42, H=30, S=3, F=8, G=8, region=1404),
+    dict(N=5, W=13, H=9, S=4, F=33, G=3, region=1404),
+    dict(N=2, W=28, H=26, S=2, F=12, G=7, region=1404),
+    # the same maps where the form does not apply: one unit pair per wave somewhere (G % 4 in {1, 2}), or no gain
+    dict(N=3, W=28, H=28, S=3, F=16, G=6, region=807),
+    dict(N=2, W=56, H=56, S=2, F=8, G=4, region=808),
+])
+def test_gather_dot_region_forms(shape, monkeypatch):
+    from dau_conv import _capi
+    rs = np.random.RandomState(17)
+    N, S, F, G, H, W = (shape[q] for q in ("N", "S", "F", "G", "H", "W"))
+    x = rs.rand(N, S, H, W).astype(np.float32)
+    dy = rs.randn(N, F, H, W).astype(np.float32)
+    w = (rs.randn(1, S, G, F) * 0.1).astype(np.float32)
+    mu1 = rs.uniform(-3.9, 3.9, (1, S, G, F)).astype(np.float32)
+    mu2 = rs.uniform(-3.9, 3.9, (1, S, G, F)).astype(np.float32)
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=_capi.FLAG_USE_INTERPOLATION | _capi.FLAG_UNIT_TESTING)
+    assert plan.info["dot_region"] == shape["region"], plan.info
+    sigma = torch.full((1, S, G, F), 0.5, device="cuda")
+    got = plan.backward(_dev(x), _dev(dy), _dev(w), _dev(mu1), _dev(mu2), sigma)
+    plan.check_status()
+    want = orc.backward(x, dy, w, mu1, mu2, 0.5, unit_testing=True)
+    for t, key in zip(got, ("dx", "dw", "dmu1", "dmu2", "dsigma")):
+        assert_parity(t.cpu().numpy(), want[key], key)
+    if shape["region"] == 1404:
+        # the 8-column form of the same plan (DAU_DOT_RW=8 at plan creation) agrees to rounding
+        monkeypatch.setenv("DAU_DOT_RW", "8")
+        plan8 = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=_capi.FLAG_USE_INTERPOLATION | _capi.FLAG_UNIT_TESTING)
+        assert plan8.info["dot_region"] in (807, 808), plan8.info
+        got8 = plan8.backward(_dev(x), _dev(dy), _dev(w), _dev(mu1), _dev(mu2), sigma)
+        for a8, a14, key in zip(got8[1:], got[1:], ("dw", "dmu1", "dmu2", "dsigma")):
+            assert_parity(a14.cpu().numpy(), a8.cpu().numpy(), key + " (14 x 4 vs 8-column regions)")
+
+
 def test_calls_on_a_side_stream():
     """Every kernel is launched on the stream handed to the ABI (no default-stream work, no device-wide sync)."""
     from dau_conv import _capi

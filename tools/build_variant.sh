@@ -6,7 +6,7 @@ name=$1; src=$2; flags=$3
 cd "$(dirname "$0")/../dau-convnet_amd/csrc"
 make -s -j8 >/dev/null
 mkdir -p ../../build/$name
-/opt/rocm/bin/hipcc -O3 -std=c++20 -fPIC --offload-arch=gfx950 -I../../include -I. -fvisibility=hidden $flags -c $src -o ../../build/$name/variant.o
+/opt/rocm/bin/hipcc -O3 -std=c++20 -fPIC --offload-arch=gfx950 -I../../include -I. -fvisibility=hidden -mllvm -pragma-unroll-threshold=1000000 $flags -c $src -o ../../build/$name/variant.o
 objs=""
 for o in dau_conv_api k_filters k_units k_direct k_gather_mfma k_gather_dot k_dense_bf16; do
   if [ "$o.hip" = "$src" ]; then objs="$objs ../../build/$name/variant.o"; else objs="$objs $o.o"; fi
