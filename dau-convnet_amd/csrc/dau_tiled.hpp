@@ -65,6 +65,7 @@ struct TiledDotConfig {
                       // one window the units are binned by window on the device and a window pass visits only its own
     bool as1, one_tile;   // tuning choices read from the environment at plan creation
     bool rw8;             // DAU_DOT_RW=8 at plan creation: 8-column regions only
+    bool ring;            // window passes keep the error tile as a ring of rows (k_gather_dot.hip, RING)
     int region_cols, region_rows;   // positions per (item, input channel) sweep: 8 x 8, 8 x 7, 14 x 4 (or 8 x 4 in bucket 18)
     int rounds;           // DAU_DOT_ROUNDS at plan creation: workgroups per CU the chunking aims at (0: default)
     bool bf16;            // x and dy are bfloat16

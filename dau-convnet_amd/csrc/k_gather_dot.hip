@@ -517,7 +517,9 @@ __device__ __forceinline__ f4 mfma_bcast(float a, float b, f4 c, int abid) {
 // BINNED: window pass over compacted unit slots (dot_params_binned_kernel): a lane's unit index comes with its
 // parameters, input channels whose slots are all empty are skipped by the wave, and a workgroup without any unit leaves.
 // RW: columns per region (8, or 14 with RH = 4); the Xk ring has one slot per 16 positions of the region in row-major order
-template <int GP, int AS, int RH, bool BINNED = false, int RW = 8>
+// RING (window passes; one error tile fills the LDS): the items of a chunk walk DOWN the columns of regions and the tile is a
+// ring of rows, so that an item loads only the RH new rows of its tile (4 of 23 in bucket 18) instead of all of them.
+template <int GP, int AS, int RH, bool BINNED = false, int RW = 8, bool RING = false>
 __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) gather_dot_kernel(const DotArgs a) {
     constexpr int kRH = RH;
     constexpr int kRW = RW;                       // (shadows the namespace constant)
@@ -554,6 +556,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     // per-lane parameters of the wave's AS x GP units, resident in registers for the whole kernel
     f2 bw[AS][GP][2];
     unsigned base[AS][GP];
+    int brow[AS][GP];           // RING: the lane's first tile row (base then holds the offset inside a row)
     int gidx[AS][GP];           // BINNED: the lane's unit g, -1 for an empty slot
     int s_of[AS];
     bool act[AS];               // BINNED: some lane of the wave has a unit of input channel si (wave-uniform)
@@ -569,6 +572,12 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
             bw[si][gp][0] = f2{p[0], p[1]};
             bw[si][gp][1] = f2{p[2], p[3]};
             base[si][gp] = (unsigned)__float_as_int(p[4]);
+            if constexpr (RING) {
+                // tile row and byte offset inside the row (the row lives in a ring slot that changes from item to item)
+                const unsigned rb = (unsigned)a.epitch * kDF * 8;
+                brow[si][gp] = (int)(base[si][gp] / rb);
+                base[si][gp] -= (unsigned)brow[si][gp] * rb;
+            }
             gidx[si][gp] = BINNED ? __float_as_int(p[5]) : 0;
         }
         if constexpr (BINNED) {
@@ -608,7 +617,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     const unsigned pieces = tile_bytes >> 10;
     auto tile_src = [&](int item) -> const char* {
         const int np = item / regions, reg = item % regions;
-        const int ry = reg / a.rx, rx = reg % a.rx;
+        const int ry = RING ? reg % a.ry : reg / a.rx, rx = RING ? reg / a.ry : reg % a.rx;
         return a.ep + ((((size_t)np * a.nfb + fb) * a.EY + (size_t)(ry * kRH + sub_dy)) * a.EX + (size_t)(rx * kRW + sub_dx)) * (kDF * 8);
     };
     // whole tile at once (first item; single-tile mode)
@@ -621,6 +630,22 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
             if (trow >= (unsigned)a.erows) trow = a.erows - 1;        // tail padding: re-read a valid row
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)trow * a.EX * (kDF * 8) + within),
                                              (lds_ptr_t)(smem + buf * tile_bytes + piece * 1024), 16, 0, 0);
+        }
+    };
+    // RING: the RH new rows of the tile of `item` (the region below the previous item's) into the ring slots the previous
+    // tile's first RH rows occupied (origin = ring slot of the previous tile's row 0).  Row by row: a row is not a whole number
+    // of KiB pieces, and a piece must be contiguous in LDS.
+    auto issue_rows = [&](int item, int origin) {
+        const char* src = tile_src(item);
+        const unsigned row_pieces = (row_bytes + 1023) >> 10;
+        for (unsigned u = wave; u < (unsigned)kRH * row_pieces; u += kDWaves) {
+            const unsigned rr = u / row_pieces, pc = u - rr * row_pieces;
+            int slot = origin + (int)rr;
+            slot = slot >= a.erows ? slot - a.erows : slot;
+            const unsigned within = pc * 1024 + lane * 16;
+            if (within < row_bytes)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)(a.erows - kRH + rr) * a.EX * (kDF * 8) + within),
+                                                 (lds_ptr_t)(smem + (unsigned)slot * row_bytes + pc * 1024), 16, 0, 0);
         }
     };
     // Two-tile mode only exists for the 17 x 17 position tile of bucket R = 4 (host: nbuf == 2 <=> Rt == 4).  There every
@@ -668,7 +693,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     };
     auto sweep_ptr = [&](int item, int s) -> const char* {
         const int np_ = item / regions, reg_ = item % regions;
-        const int ry_ = reg_ / a.rx, rx_ = reg_ % a.rx;
+        const int ry_ = RING ? reg_ % a.ry : reg_ / a.rx, rx_ = RING ? reg_ / a.ry : reg_ % a.rx;
         return reinterpret_cast<const char*>(a.xk) +
                ((((size_t)np_ * a.s_pad + s) * a.Hp + (size_t)ry_ * kRH) * a.Wp + (size_t)rx_ * kRW) * 32;
     };
@@ -689,6 +714,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
             for (int i = 0; i < kXSlots; ++i) x_fetch(xr[i], x0, i);
         }
     }
+    int origin = 0;             // RING: ring slot of the current tile's row 0
     for (int item = item0; item < item1; ++item) {
         const bool two = a.nbuf == 2;
         const int buf = two ? (item - item0) & 1 : 0;
@@ -726,10 +752,24 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
             f2 eb[2][GP][2][GS];         // [buffer parity][unit pair][row: 0 = tile row j (dy=1), 1 = row j+1 (dy=0)][col]
             f2 epn[GP][2];               // column 0 of a row (precedes its first group)
             unsigned rowaddr[GP], rowaddr2[GP];
+            int slot2[GP];               // RING: ring slot of rowaddr2's tile row
+            // address of the tile row below rowaddr2's
+            auto row_below = [&](int gp) -> unsigned {
+                if constexpr (RING) return slot2[gp] + 1 == a.erows ? base[si][gp] : rowaddr2[gp] + row_bytes;
+                else return rowaddr2[gp] + row_bytes;
+            };
 #pragma unroll
             for (int gp = 0; gp < GP; ++gp) {
-                rowaddr[gp] = base[si][gp] + bufoff;
-                rowaddr2[gp] = rowaddr[gp] + row_bytes;
+                if constexpr (RING) {
+                    int sl = origin + brow[si][gp];
+                    sl = sl >= a.erows ? sl - a.erows : sl;
+                    rowaddr[gp] = (unsigned)sl * row_bytes + base[si][gp];
+                    slot2[gp] = sl + 1 == a.erows ? 0 : sl + 1;
+                    rowaddr2[gp] = (unsigned)slot2[gp] * row_bytes + base[si][gp];
+                } else {
+                    rowaddr[gp] = base[si][gp] + bufoff;
+                    rowaddr2[gp] = rowaddr[gp] + row_bytes;
+                }
                 lds_read(epn[gp][0], rowaddr[gp], 0);
                 lds_read(epn[gp][1], rowaddr2[gp], 0);
 #pragma unroll
@@ -757,7 +797,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     } else if (j + 1 < kRH) {                                                                                       \
         /* first group of the next row: tile rows j+1 and j+2 (rowaddr2 / rowaddr2 + pitch), columns 0..GS */       \
         _Pragma("unroll") for (int gp = 0; gp < GP; ++gp) {                                                         \
-            const unsigned r3 = rowaddr2[gp] + row_bytes;                                                           \
+            const unsigned r3 = row_below(gp);                                                                      \
             if (col == 0) {                                                                                         \
                 lds_read(epn[gp][0], rowaddr2[gp], 0);                                                              \
                 lds_read(epn[gp][1], r3, 0);                                                                        \
@@ -855,12 +895,29 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                 }
                 // next row: tile rows shift down by one
 #pragma unroll
-                for (int gp = 0; gp < GP; ++gp) { rowaddr[gp] = rowaddr2[gp]; rowaddr2[gp] += row_bytes; }
+                for (int gp = 0; gp < GP; ++gp) {
+                    if constexpr (RING) {
+                        const unsigned below = row_below(gp);
+                        rowaddr[gp] = rowaddr2[gp]; rowaddr2[gp] = below;
+                        slot2[gp] = slot2[gp] + 1 == a.erows ? 0 : slot2[gp] + 1;
+                    } else {
+                        rowaddr[gp] = rowaddr2[gp]; rowaddr2[gp] += row_bytes;
+                    }
+                }
             }
         }
         if (!two && item + 1 < item1) {
             __syncthreads();            // every wave is done with the only tile
-            if (!(a.debug & 2)) issue(item + 1, 0);
+            if constexpr (RING) {
+                // the next item is the region below (same image pair, same column of regions): its tile shares all but RH
+                // rows with this one
+                const bool below = (item + 1) % regions != 0 && ((item + 1) % regions) % a.ry != 0;
+                if (a.debug & 2) { origin = 0; }
+                else if (below) { issue_rows(item + 1, origin); origin = origin + kRH >= a.erows ? origin + kRH - a.erows : origin + kRH; }
+                else { issue(item + 1, 0); origin = 0; }
+            } else {
+                if (!(a.debug & 2)) issue(item + 1, 0);
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -916,20 +973,27 @@ void blur4_plan(int k, int Hp, int Wp, int* wy, int* wx, size_t* lds) {
 }
 
 // a == nullptr: raise the kernel's dynamic-LDS limit (once per plan and device, tiled_dot_init); else launch
-template <int GP, int AS, int RH, bool BINNED = false, int RW = 8>
+template <int GP, int AS, int RH, bool BINNED = false, int RW = 8, bool RING = false>
 void launch_dot(hipStream_t st, const DotArgs* a, int grid, size_t lds) {
-    auto kern = gather_dot_kernel<GP, AS, RH, BINNED, RW>;
+    auto kern = gather_dot_kernel<GP, AS, RH, BINNED, RW, RING>;
     if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kDWaves * 64), lds, st, *a);
 }
 
-void dispatch_dot(bool binned, int RW, int RH, int GP, int AS, hipStream_t st, const DotArgs* a, int grid, size_t lds) {
+void dispatch_dot(bool binned, bool ring, int RW, int RH, int GP, int AS, hipStream_t st, const DotArgs* a, int grid, size_t lds) {
     if (RW == 14) {                                  // 14 x 4 regions: unit blocks of four only (make_dot_geometry)
         if (AS == 2) launch_dot<2, 2, 4, false, 14>(st, a, grid, lds);
         else launch_dot<2, 1, 4, false, 14>(st, a, grid, lds);
         return;
     }
     if (binned) {
+        // window passes: the tile is a ring of rows (DAU_DOT_RING=0 at plan creation: whole tiles, for A/B)
+        if (ring) {
+            if (RH == 8) launch_dot<1, 4, 8, true, 8, true>(st, a, grid, lds);
+            else if (RH == 4) launch_dot<1, 4, 4, true, 8, true>(st, a, grid, lds);
+            else launch_dot<1, 4, 7, true, 8, true>(st, a, grid, lds);
+            return;
+        }
         if (RH == 8) launch_dot<1, 4, 8, true>(st, a, grid, lds);
         else if (RH == 4) launch_dot<1, 4, 4, true>(st, a, grid, lds);
         else launch_dot<1, 4, 7, true>(st, a, grid, lds);
@@ -968,6 +1032,7 @@ bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, int igno
     TiledDotConfig c{};
     c.sh = sh; c.R = R; c.blur_k = blur_k; c.NP = (sh.N + 1) / 2; c.variant = g.npass; c.windows = g.nsub1 * g.nsub1;
     c.bf16 = bf16; c.ignore = ignore;
+    c.ring = g.nsub1 > 1 && g.nbuf == 1 && !(getenv("DAU_DOT_RING") && atoi(getenv("DAU_DOT_RING")) == 0);
     c.as1 = as1; c.one_tile = one_tile; c.rounds = rounds; c.rw8 = rw8; c.region_cols = g.RW; c.region_rows = g.RH; c.debug = getenv("DAU_DOT_DEBUG") ? atoi(getenv("DAU_DOT_DEBUG")) : 0;
     *cfg = c;
     return true;
@@ -979,7 +1044,7 @@ size_t tiled_dot_workspace_bytes(const TiledDotConfig& c) {
 
 void tiled_dot_init(const TiledDotConfig& c) {
     const DotGeometry g = make_dot_geometry(c.sh, c.R, c.as1, c.one_tile, c.rounds, c.rw8);
-    for (int i = 0; i < g.npass; ++i) dispatch_dot(g.nsub1 > 1, g.RW, g.RH, g.pass[i].GP, g.pass[i].AS, nullptr, nullptr, 0, 0);
+    for (int i = 0; i < g.npass; ++i) dispatch_dot(g.nsub1 > 1, c.ring, g.RW, g.RH, g.pass[i].GP, g.pass[i].AS, nullptr, nullptr, 0, 0);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pack_error_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blur4_pack_for(c.blur_k)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
@@ -1057,7 +1122,7 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
         a.params = reinterpret_cast<const float*>(ws + l.params_off + ps.params_off);
         a.g_begin = ps.g_begin; a.nsb = ps.nsb; a.ngb = ps.ngb; a.chunks = ps.chunks;
         const int grid = ps.chunks * g.nsub1 * g.nsub1 * g.nfb * ps.ngb * ps.nsb;
-        dispatch_dot(binned, g.RW, g.RH, ps.GP, ps.AS, st, &a, grid, lds);
+        dispatch_dot(binned, c.ring, g.RW, g.RH, ps.GP, ps.AS, st, &a, grid, lds);
     }
     const long n = (long)kNumK * s.S * s.G * s.F;
     const int rgrid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
