@@ -209,7 +209,10 @@ struct BlurPackArgs {
 
 // K: compile-time prefilter support (taps live in SGPRs, tap loops unrolled); K = 0: any support, taps re-read per use
 template <int K>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6))) blur_pack_kernel(const BlurPackArgs a) {
+#ifndef DAU_BLUR_WAVES_PER_EU
+#define DAU_BLUR_WAVES_PER_EU 6
+#endif
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(DAU_BLUR_WAVES_PER_EU))) blur_pack_kernel(const BlurPackArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     if (!guard_pass(a.guard)) return;
     const int C = a.C, H = a.H, W = a.W, R = a.R, k = K ? K : a.k;
@@ -851,10 +854,13 @@ size_t blur_pack_lds_bytes(const Geometry& g, int k, int band_rows = 0) {
     return ((wh + k - 1) * (ww + k - 1) + (wh + k - 1) * ww + strip) * 8;
 }
 
-// planes that need more than ~40 KiB of LDS are staged in two (or more) row bands
+// planes that need more than 80 KiB of LDS (two workgroups per CU) are staged in two (or more) row bands.  (Round 1 found
+// 40 KiB bands faster; with the loads of a workgroup in flight together the whole plane per workgroup is: 56-pixel planes
+// 382 -> 350 us, the 68 x 104 planes of bucket 18 1784 -> 1594 us -- every band re-reads its blur halo.)
 int blur_pack_bands(const Geometry& g, int k) {
     int bands = 1;
-    while (bands < 8 && blur_pack_lds_bytes(g, k, (g.rows + bands - 1) / bands) > 40 * 1024) ++bands;
+    static const size_t limit = getenv("DAU_BLUR_LDS_KB") ? (size_t)atoi(getenv("DAU_BLUR_LDS_KB")) * 1024 : 80 * 1024;   // (env: timing experiments)
+    while (bands < 8 && blur_pack_lds_bytes(g, k, (g.rows + bands - 1) / bands) > limit) ++bands;
     return bands;
 }
 
@@ -924,7 +930,8 @@ void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in,
     if (bands > 1) b.ppb = 1;
     b.planes = c.NP * c.patches * c.Cin * bands;
     b.lds_plane_floats = (unsigned)(blur_lds / 4);
-    hipLaunchKernelGGL(kern, dim3((b.planes + b.ppb - 1) / b.ppb), dim3(512), b.ppb * blur_lds, st, b);
+    static const int blur_threads = getenv("DAU_BLUR_THREADS") ? atoi(getenv("DAU_BLUR_THREADS")) : 512;                  // timing experiments
+    hipLaunchKernelGGL(kern, dim3((b.planes + b.ppb - 1) / b.ppb), dim3(b.ppb > 1 ? 512 : blur_threads), b.ppb * blur_lds, st, b);
     const int nfb = (c.Cout + g.fb - 1) / g.fb;
     const bool binned = g.nwin1 > 1;
     const size_t uts = ut_stride_bytes(c.G, g.fb, binned);
