@@ -117,12 +117,26 @@ def launch_ranks(args):
     return rc
 
 
-def lib_fingerprint():
-    path = os.path.join(ROOT, "dau-convnet_amd", "dau_conv", "libdau_conv_hip.so")
+def source_fingerprint():
+    """sha-256 prefix over the kernel sources, computed as the Makefile does for the library's build id (file names and
+    contents of csrc/*.hip, *.hpp, Makefile in sorted order, then include/dau_conv.h)."""
     h = hashlib.sha256()
-    with open(path, "rb") as f:
+    csrc = os.path.join(ROOT, "dau-convnet_amd", "csrc")
+    for name in sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".hpp")) or f == "Makefile"):
+        h.update(name.encode())
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(f.read())
+    with open(os.path.join(ROOT, "include", "dau_conv.h"), "rb") as f:
         h.update(f.read())
     return h.hexdigest()[:16]
+
+
+def lib_fingerprint():
+    """Build id of the LOADED library (dau_conv_build_id: the source fingerprint the Makefile compiled in).  Not a hash of
+    the binary: hipcc derives symbol names from the source path, so the same sources built in another directory (the
+    GPU box's copy, a fresh clone) give another binary."""
+    from dau_conv import _capi
+    return _capi.build_id()
 
 
 def measured_traffic(workload_key, io, dominant):
@@ -137,7 +151,7 @@ def measured_traffic(workload_key, io, dominant):
     run = pmc.get("runs", {}).get("%s/%s" % (workload_key, io))
     if run is None:
         return None, "no PMC pass committed for workload %s/%s" % (workload_key, io)
-    if run.get("lib_sha256_16") != lib_fingerprint():
+    if run.get("src_sha256_16") != lib_fingerprint():
         return None, "committed PMC pass is from another build of the library (stale)"
     key = {"gather_dot": "dau::gather_dot_kernel", "gather_sum_fwd": "dau::gather_mfma_kernel",
            "gather_sum_dx": "dau::gather_mfma_kernel"}.get(dominant, "")

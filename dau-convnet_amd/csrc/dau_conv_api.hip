@@ -279,6 +279,11 @@ extern "C" {
 
 int dau_conv_abi_version(void) { return DAU_CONV_ABI_VERSION; }
 
+#ifndef DAU_BUILD_ID
+#define DAU_BUILD_ID "unknown"
+#endif
+const char* dau_conv_build_id(void) { return DAU_BUILD_ID; }
+
 const char* dau_conv_last_error(void) { return g_last_error.c_str(); }
 
 int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {

@@ -70,6 +70,7 @@ def _load():
     vp, fp, ip = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p
     lib.dau_conv_abi_version.restype = ctypes.c_int
     lib.dau_conv_last_error.restype = ctypes.c_char_p
+    lib.dau_conv_build_id.restype = ctypes.c_char_p
     lib.dau_conv_plan_create.argtypes = [ctypes.POINTER(_Desc), ctypes.POINTER(vp)]
     lib.dau_conv_plan_destroy.argtypes = [vp]
     lib.dau_conv_plan_get_info.argtypes = [vp, ctypes.POINTER(_Info)]
@@ -90,6 +91,11 @@ def _load():
 
 
 lib = _load()
+
+
+def build_id():
+    """Fingerprint of the kernel sources the loaded library was built from (dau_conv_build_id)."""
+    return lib.dau_conv_build_id().decode()
 
 
 def _check(code):

@@ -174,6 +174,9 @@ typedef struct dau_conv_plan_info {
 } dau_conv_plan_info;
 
 DAU_API int dau_conv_abi_version(void);
+/* sha-256 prefix (16 hex digits) over the kernel sources this library was built from (the .hip and .hpp files of csrc, its Makefile, this
+ * header), set by the Makefile: measurement files (profiles/) name the build they were taken from by it. */
+DAU_API const char *dau_conv_build_id(void);
 DAU_API const char *dau_conv_last_error(void); /* thread-local message of the last failing call */
 
 DAU_API int dau_conv_plan_create(const dau_conv_desc *desc, dau_conv_plan **plan_out);

@@ -22,7 +22,7 @@ def test_header_declares_expected_entry_points():
                  "dau_conv_backward", "dau_conv_check_status", "dau_conv_last_error", "dau_conv_abi_version",
                  "dau_conv_backward_param_sums", "dau_conv_finalize_param_grads", "dau_conv_last_status",
                  "dau_conv_filters", "dau_conv_unit_table", "dau_conv_plan_get_info", "dau_conv_profile_begin",
-                 "dau_conv_profile_end"):
+                 "dau_conv_profile_end", "dau_conv_build_id"):
         assert must in names
 
 
@@ -32,6 +32,14 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), "missing export %s" % name
     assert lib.dau_conv_abi_version() == 2
+
+
+def test_build_id_is_the_fingerprint_of_the_sources():
+    """The library names the sources it was built from (bench.py matches committed counter files by it); the Makefile and
+    bench.source_fingerprint() must compute the same thing, wherever the tree lies."""
+    import bench
+    from dau_conv import _capi
+    assert len(_capi.build_id()) == 16 and _capi.build_id() == bench.source_fingerprint()
 
 
 def test_plan_validation_without_device():

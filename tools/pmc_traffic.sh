@@ -37,12 +37,14 @@ for k, v in acc.items():
 for family, passes in (("dau::gather_mfma_kernel", 2), ("dau::gather_dot_kernel", 1)):
     if family in fam:
         kern[family] = dict(hbm_bytes_per_pass=fam[family] / passes, passes_per_step=passes)
-lib = hashlib.sha256(open("dau-convnet_amd/dau_conv/libdau_conv_hip.so", "rb").read()).hexdigest()[:16]
+sys.path.insert(0, ".")
+import bench
+lib = bench.lib_fingerprint()          # the library's build id = fingerprint of its sources (path independent), see bench.py
 doc = {"_comment": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes, no trace domains) of `python3 bench.py "
        "--steps %d --warmup %d --no-cpu-baseline --no-layer --workload %s --io %s %s`, MI355X. Counter unit KiB per dispatch, summed "
        "over the run and divided by its %d steps. hbm bytes apply the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE "
        "reports half of a wide coalesced read): 2*FETCH + WRITE." % (steps, warm, wl, io, extra, nsteps),
-       "runs": {"%s/%s" % (wl, io): {"lib_sha256_16": lib, "kernels": kern,
+       "runs": {"%s/%s" % (wl, io): {"src_sha256_16": lib, "kernels": kern,
                                       "step_total_hbm_bytes": sum(v["hbm_bytes_per_step"] for v in kern.values() if "hbm_bytes_per_step" in v)}}}
 json.dump(doc, open("gpurun_out/%s_pmc_traffic.json" % tag, "w"), indent=1)
 for k, v in sorted(kern.items(), key=lambda kv: -kv[1].get("hbm_bytes_per_step", 0))[:9]:
