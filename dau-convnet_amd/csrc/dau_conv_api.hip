@@ -83,6 +83,9 @@ struct BucketSet {
     TiledDotConfig tiled_dot;
     // DAU_FLAG_DENSE_BF16, bucket 4 only: the gather-sum passes run as a densified bf16 implicit GEMM (k_dense_bf16.hip)
     bool dense_ok = false;
+    // ... and, from five units on, the parameter gradients as dense correlations on the same matrix cores (k_dense_wgrad.hip)
+    bool wgrad_ok = false;
+    WgradConfig wgrad;
     DenseConfig dense_fwd, dense_dx;
     // Batch slabs.  Every pass stages its whole input before it gathers; where that staged copy would exceed the workspace
     // budget (DAU_WORKSPACE_BUDGET_GB at plan creation, default 12: only the 512 x 512 configurations get there) the pass
@@ -191,6 +194,7 @@ int ensure_attrs(const dau_conv_plan* p) {
         if (p->sets[i].fwd_ok) { tiled_gather_init(p->sets[i].tiled_fwd); tiled_gather_init(p->sets[i].tiled_dx); }
         if (p->sets[i].dot_ok) tiled_dot_init(p->sets[i].tiled_dot);
         if (p->sets[i].dense_ok) { dense_gather_init(p->sets[i].dense_fwd); dense_gather_init(p->sets[i].dense_dx); }
+        if (p->sets[i].wgrad_ok) dense_wgrad_init(p->sets[i].wgrad);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return fail(DAU_INTERNAL, "raising the dynamic-LDS limit of the bucket-%d kernels failed: %s", p->sets[i].bucket,
@@ -255,6 +259,8 @@ BwdWs carve_backward(const dau_conv_plan* p, void* ws) {
         size_t need = 0;
         for (int i = 0; i < p->nsets; ++i)
             if (p->sets[i].dot_ok) need = std::max(need, tiled_dot_workspace_bytes(p->sets[i].tiled_dot));
+        for (int i = 0; i < p->nsets; ++i)
+            if (p->sets[i].wgrad_ok) need = std::max(need, dense_wgrad_workspace_bytes(p->sets[i].wgrad));
         w.tiled_dot = c.take<char>(need);
     } else {
         w.xk4 = c.take<float>((size_t)kNumK * s.N * s.S * s.H * s.W);
@@ -366,6 +372,16 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
         };
         bs.slab_gather = pick_slab(configure_gather);
         bs.slab_dot = pick_slab(configure_dot);
+        {
+            // dense parameter gradients: the bf16 layer's bucket-4 set, whole batch in one slab, three or more units (its cost
+            // does not depend on the unit count: 15.3 ms at the north-star size against 16.0 ms for the exact gather-dot of a
+            // four-unit block, 9.7 ms of two units); DAU_DENSE_WGRAD=0 / 1: never / from one unit on (A/B and tests)
+            const char* wenv = getenv("DAU_DENSE_WGRAD");
+            const int min_units = wenv ? (atoi(wenv) == 0 ? 1 << 30 : 1) : 3;
+            bs.wgrad_ok = want_dense && bf16 && b == 4 && bs.dense_ok && bs.dot_ok && bs.slab_dot == s.N && s.G >= min_units &&
+                          dense_wgrad_configure(s, blur_k, bf16, &bs.wgrad) &&
+                          (double)dense_wgrad_workspace_bytes(bs.wgrad) <= budget_bytes;
+        }
     }
     if ((desc->flags & DAU_FLAG_DENSE_BF16) && !bf16) {
         delete p;
@@ -450,7 +466,7 @@ int dau_conv_plan_get_info(const dau_conv_plan* plan, dau_conv_plan_info* info) 
     info->dot_windows = plan->algo_bwd == DAU_ALGO_TILED ? plan->top().tiled_dot.windows : 0;
     info->gather_windows = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.windows : 0;
     info->bucket_sets = plan->dynamic ? plan->nsets : 1;
-    info->gather_dense_bf16 = plan->sets[0].dense_ok ? 1 : 0;
+    info->gather_dense_bf16 = plan->sets[0].dense_ok ? (plan->sets[0].wgrad_ok ? 2 : 1) : 0;
     info->batch_slab_gather = plan->top().slab_gather;
     info->batch_slab_dot = plan->top().slab_dot;
     info->dot_region = plan->top().dot_ok ? plan->top().tiled_dot.region_cols * 100 + plan->top().tiled_dot.region_rows : 0;
@@ -529,6 +545,11 @@ int run_param_sums(const dau_conv_plan* p, hipStream_t st, const float* x, const
         for (int ci = 0; ci < ncand; ++ci) {
             const BucketSet& bs = *cand[ci].set;
             const TiledDotConfig& cfg = bs.tiled_dot;
+            if (bs.wgrad_ok) {                                                 // bf16 layer, offsets within +-4, many units
+                ProfScope prof(p, 2, st);
+                dense_wgrad_run(st, bs.wgrad, x, dy, ws.filters, ws.table_bare, p->drop_col, p->drop_row, r4, ws.tiled_dot, cand[ci].guard);
+                continue;
+            }
             for (int n0 = 0; n0 < s.N; n0 += bs.slab_dot) {                // the sums of the slabs add up in r4
                 tiled_dot_prepare(st, cfg, slab_ptr(x, (size_t)n0 * s.S * s.H * s.W, esize),
                                   slab_ptr(dy, (size_t)n0 * s.F * s.H * s.W, esize), ws.filters, ws.table_bare, p->drop_col,

@@ -83,4 +83,28 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& cfg, const float* x
 void tiled_dot_run(hipStream_t st, const TiledDotConfig& cfg, float* r4, void* workspace, const Guard& guard, bool accumulate);
 void tiled_dot_init(const TiledDotConfig& cfg);
 
+// The four derivative-filtered copies of x, staged position-major (k_gather_dot.hip): x[N,C,H,W] -> xk[NP][cstride][Hp][Wp][4][2]
+void launch_blur4_pack(hipStream_t st, const float* x, const float* filters, int N, int C, int cstride, int H, int W, int Hp,
+                       int Wp, int blur_k, bool bf16, float* xk, const Guard& guard);
+void blur4_pack_init(int blur_k);
+bool blur4_pack_fits(int blur_k, int Hp, int Wp);
+
+// Densified parameter gradients on the bf16 matrix cores (k_dense_wgrad.hip; DAU_FLAG_DENSE_BF16, bucket 4, bfloat16
+// activations, five or more units): C_k[d][s][f] = sum_{n,q} Xk[n,s,q+d] * E'[n,f,q] for the 10 x 10 displacements d as a GEMM
+// with K = (image, position), then r_k[u] = sum_taps b_t(u) * C_k[o_u + t].
+struct WgradConfig {
+    Shape sh;
+    int blur_k;
+    int SB, FB, NC;       // 32-channel blocks of S and F, 16-image chunks of N
+    int HsT, WsT, WT;     // staged Xk plane (H+9 rows, WT+9 columns rounded up to 8) and error row (an instantiated length >= W)
+    int splits;           // the image chunks are cut into `splits` ranges (partial sums per range)
+    int Hp, Wp;           // plane of the intermediate fp32 copy (blur4_pack)
+};
+bool dense_wgrad_configure(const Shape& sh, int blur_k, bool bf16, WgradConfig* cfg);
+size_t dense_wgrad_workspace_bytes(const WgradConfig& cfg);
+void dense_wgrad_init(const WgradConfig& cfg);
+// r4[k][s][g][f] = raw parameter-gradient sums; x, dy bfloat16 NCHW; table = bare unit table [S][G][F]
+void dense_wgrad_run(hipStream_t st, const WgradConfig& cfg, const float* x, const float* dy, const float* filters,
+                     const UnitRef* table, int drop_col, int drop_row, float* r4, void* workspace, const Guard& guard);
+
 }  // namespace dau

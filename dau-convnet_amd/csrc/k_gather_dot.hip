@@ -1015,6 +1015,34 @@ auto blur4_pack_for(int blur_k) {
 
 }  // namespace
 
+// x[N,C,H,W] -> xk[NP][cstride][Hp][Wp][4 kinds][2 images] (fp32), zero beyond the image and in the channel slots C..cstride-1
+void launch_blur4_pack(hipStream_t st, const float* x, const float* filters, int N, int C, int cstride, int H, int W, int Hp,
+                       int Wp, int blur_k, bool bf16, float* xk, const Guard& guard) {
+    int wy, wx; size_t blur_lds;
+    blur4_plan(blur_k, Hp, Wp, &wy, &wx, &blur_lds);
+    auto kern = blur4_pack_for(blur_k);
+    Blur4Args b{};
+    b.guard = guard;
+    b.in = x; b.taps = filters + kTaps1dOffset; b.xk = xk;
+    b.N = N; b.C = C; b.cstride = cstride; b.H = H; b.W = W; b.k = blur_k; b.Hp = Hp; b.Wp = Wp; b.bf16 = bf16 ? 1 : 0;
+    b.WY = wy; b.WX = wx; b.nwy = (Hp + wy - 1) / wy; b.nwx = (Wp + wx - 1) / wx;
+    // small windows: several per workgroup, so that the 512 threads have rows to share
+    const int elems = wy * wx;
+    b.ppb = elems >= 2048 ? 1 : elems >= 1024 ? 2 : elems >= 512 ? 4 : 8;
+    while (b.ppb > 1 && b.ppb * blur_lds > 64 * 1024) b.ppb /= 2;
+    b.items = ((N + 1) / 2) * b.nwy * b.nwx * cstride;
+    b.lds_item_floats = (unsigned)(blur_lds / 4);
+    hipLaunchKernelGGL(kern, dim3((b.items + b.ppb - 1) / b.ppb), dim3(512), b.ppb * blur_lds, st, b);
+}
+void blur4_pack_init(int blur_k) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blur4_pack_for(blur_k)), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+bool blur4_pack_fits(int blur_k, int Hp, int Wp) {
+    int wy, wx; size_t blur_lds;
+    blur4_plan(blur_k, Hp, Wp, &wy, &wx, &blur_lds);
+    return blur_lds <= 150 * 1024;
+}
+
 bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, int ignore, TiledDotConfig* cfg) {
     // timing experiments: DAU_DOT_AS1 (one input channel per wave), DAU_DOT_NBUF=1 (one error tile), DAU_DOT_DEBUG
     const bool as1 = getenv("DAU_DOT_AS1") != nullptr;
@@ -1064,24 +1092,8 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
         hipLaunchKernelGGL(pack_error_kernel, dim3(c.NP * g.nfb * g.EY * nxc), dim3(256), lds, st, dy, s.N, s.F, s.H, s.W, g.Rp, g.EX,
                            g.EY, g.nfb, drop_col, drop_row, c.bf16 ? 1 : 0, reinterpret_cast<float*>(ws + l.ep_off), guard);
     }
-    {
-        // channel slots beyond S (padding of the last input-channel block) are written as zero planes by the kernel
-        int wy, wx; size_t blur_lds;
-        blur4_plan(c.blur_k, g.Hp, g.Wp, &wy, &wx, &blur_lds);
-        auto kern = blur4_pack_for(c.blur_k);
-        Blur4Args b{};
-        b.guard = guard;
-        b.in = x; b.taps = filters + kTaps1dOffset; b.xk = reinterpret_cast<float*>(ws + l.xk_off);
-        b.N = s.N; b.C = s.S; b.cstride = s_pad; b.H = s.H; b.W = s.W; b.k = c.blur_k; b.Hp = g.Hp; b.Wp = g.Wp; b.bf16 = c.bf16 ? 1 : 0;
-        b.WY = wy; b.WX = wx; b.nwy = (g.Hp + wy - 1) / wy; b.nwx = (g.Wp + wx - 1) / wx;
-        // small windows: several per workgroup, so that the 512 threads have rows to share
-        const int elems = wy * wx;
-        b.ppb = elems >= 2048 ? 1 : elems >= 1024 ? 2 : elems >= 512 ? 4 : 8;
-        while (b.ppb > 1 && b.ppb * blur_lds > 64 * 1024) b.ppb /= 2;
-        b.items = c.NP * b.nwy * b.nwx * s_pad;
-        b.lds_item_floats = (unsigned)(blur_lds / 4);
-        hipLaunchKernelGGL(kern, dim3((b.items + b.ppb - 1) / b.ppb), dim3(512), b.ppb * blur_lds, st, b);
-    }
+    // channel slots beyond S (padding of the last input-channel block) are written as zero planes by the kernel
+    launch_blur4_pack(st, x, filters, s.N, s.S, s_pad, s.H, s.W, g.Hp, g.Wp, c.blur_k, c.bf16, reinterpret_cast<float*>(ws + l.xk_off), guard);
     if (g.nsub1 > 1) {
         const DotGeometry::Pass& ps = g.pass[0];
         const long total = (long)g.nsub1 * g.nsub1 * s_pad * g.nfb * kDF;

@@ -165,7 +165,8 @@ typedef struct dau_conv_plan_info {
     int32_t dot_windows;       /* tiled gather-dot: offset windows (1 for kernels <= 17)          */
     int32_t gather_windows;    /* tiled gather-sum: offset-window passes (1 for kernels <= 33)    */
     int32_t bucket_sets;       /* kernel sets a call can choose from (1: static bucket only)      */
-    int32_t gather_dense_bf16; /* 1: the bucket-4 gather-sum passes use the densified bf16 GEMM   */
+    int32_t gather_dense_bf16; /* 1: the bucket-4 gather-sum passes use the densified bf16 GEMM;
+                                  2: the parameter gradients too (three or more units, rows <= 60) */
     int32_t batch_slab_gather; /* images staged and gathered at a time by the y / dx passes and   */
     int32_t batch_slab_dot;    /* by the parameter-gradient pass of the static bucket (= batch
                                   unless the staged copy would exceed the workspace budget)      */

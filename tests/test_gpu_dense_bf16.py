@@ -35,7 +35,7 @@ def _run(plan, xb, dyb, w, mu1, mu2, calls=1):
     return y, g
 
 
-def _check(y, g, xb, dyb, w, mu1, mu2, name):
+def _check(y, g, xb, dyb, w, mu1, mu2, name, dense_params=False):
     x32, dy32 = xb.float().numpy(), dyb.float().numpy()
     want_y = orc.forward(x32, w, mu1, mu2, 0.5)
     want = orc.backward(x32, dy32, w, mu1, mu2, 0.5)
@@ -43,7 +43,10 @@ def _check(y, g, xb, dyb, w, mu1, mu2, name):
     assert_parity(y.float().cpu().numpy(), want_y, name + "/y", rel=2e-2, floor=4e-3)
     assert_parity(g[0].float().cpu().numpy(), want["dx"], name + "/dx", rel=2e-2, floor=4e-3)
     for t, key in zip(g[1:], ("dw", "dmu1", "dmu2", "dsigma")):
-        assert_parity(t.cpu().numpy(), want[key], name + "/" + key)
+        if dense_params:      # the dense correlations round Xk and the error to bfloat16: the bf16 bar
+            assert_parity(t.cpu().numpy(), want[key], name + "/" + key, rel=2e-2, floor=4e-3)
+        else:                 # exact fp32 gather-dot on the bf16 inputs: the fp32 bar
+            assert_parity(t.cpu().numpy(), want[key], name + "/" + key)
 
 
 @pytest.mark.parametrize("shape", [
@@ -62,9 +65,45 @@ def test_dense_bf16_gather_against_oracle(shape):
     mu1.flat[0] = 3.99; mu2.flat[0] = -3.99; mu1.flat[1] = -4.0; mu2.flat[1] = 4.0       # the corners of the 10 x 10 kernel
     flags = _capi.FLAG_USE_INTERPOLATION | _capi.FLAG_IO_BF16 | _capi.FLAG_DENSE_BF16
     plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=flags)
-    assert plan.info["gather_dense_bf16"] == 1
+    # three or more units (and rows of at most 60 pixels): the parameter gradients take the dense form too
+    assert plan.info["gather_dense_bf16"] == (2 if G >= 3 and W <= 60 else 1)
     y, g = _run(plan, xb, dyb, w, mu1, mu2)
-    _check(y, g, xb, dyb, w, mu1, mu2, "dense")
+    _check(y, g, xb, dyb, w, mu1, mu2, "dense", dense_params=plan.info["gather_dense_bf16"] == 2)
+
+
+@pytest.mark.parametrize("shape", [
+    dict(N=2, S=16, F=32, G=6, H=56, W=56),       # two blocks of 30 columns, whole channel blocks
+    dict(N=3, S=20, F=40, G=5, H=30, W=45),       # ragged channels, odd batch (one image pair without partner, 13 empty images)
+    dict(N=17, S=7, F=5, G=8, H=9, W=6),          # two image chunks, the second almost empty; one block of 30 columns
+    dict(N=2, S=33, F=290, G=2, H=28, W=28),      # ten 32-channel blocks of F = two workgroup groups; forced for two units
+    dict(N=36, S=8, F=8, G=1, H=12, W=60),        # three image chunks (split), the widest row the form takes
+    dict(N=4, S=40, F=24, G=9, H=14, W=31),
+])
+@pytest.mark.parametrize("unit_testing", [False, True])
+def test_dense_parameter_gradients_against_oracle(shape, unit_testing, monkeypatch):
+    """k_dense_wgrad.hip on its own: DAU_DENSE_WGRAD=1 takes the dense correlations from one unit on."""
+    from dau_conv import _capi
+    monkeypatch.setenv("DAU_DENSE_WGRAD", "1")
+    N, S, F, G, H, W = (shape[q] for q in ("N", "S", "F", "G", "H", "W"))
+    xb, dyb, w, mu1, mu2 = _case(47, N, S, F, G, H, W, 3.99)
+    mu1.flat[0] = 3.99; mu2.flat[0] = -3.99; mu1.flat[1] = -4.0; mu2.flat[1] = 4.0       # the corners of the displacement range
+    flags = _capi.FLAG_USE_INTERPOLATION | _capi.FLAG_IO_BF16 | _capi.FLAG_DENSE_BF16 | (_capi.FLAG_UNIT_TESTING if unit_testing else 0)
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=flags)
+    assert plan.info["gather_dense_bf16"] == 2
+    dev = lambda a: torch.from_numpy(a).cuda()
+    sigma = torch.full((1, S, G, F), 0.5, device="cuda")
+    got = plan.backward(xb.cuda(), dyb.cuda(), dev(w), dev(mu1), dev(mu2), sigma)
+    plan.check_status()
+    want = orc.backward(xb.float().numpy(), dyb.float().numpy(), w, mu1, mu2, 0.5, unit_testing=unit_testing)
+    for t, key in zip(got[1:], ("dw", "dmu1", "dmu2", "dsigma")):
+        assert_parity(t.cpu().numpy(), want[key], key, rel=2e-2, floor=4e-3)
+    # and against the exact gather-dot of the same plan shape (fp32 arithmetic on the same bf16 inputs)
+    monkeypatch.setenv("DAU_DENSE_WGRAD", "0")
+    exact = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=flags)
+    assert exact.info["gather_dense_bf16"] == 1
+    ref = exact.backward(xb.cuda(), dyb.cuda(), dev(w), dev(mu1), dev(mu2), sigma)
+    for a, b, key in zip(got[1:], ref[1:], ("dw", "dmu1", "dmu2", "dsigma")):
+        assert_parity(a.cpu().numpy(), b.cpu().numpy(), key + " (dense vs exact)", rel=2e-2, floor=4e-3)
 
 
 def test_dense_bf16_under_a_larger_kernel_follows_the_offsets():
@@ -74,10 +113,10 @@ def test_dense_bf16_under_a_larger_kernel_follows_the_offsets():
     N, S, F, G, H, W = 3, 18, 36, 4, 33, 40
     flags = _capi.FLAG_USE_INTERPOLATION | _capi.FLAG_IO_BF16 | _capi.FLAG_DENSE_BF16
     plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=17, sigma_hint=0.5, flags=flags)
-    assert plan.info["gather_dense_bf16"] == 1 and plan.info["bucket_sets"] == 2
+    assert plan.info["gather_dense_bf16"] == 2 and plan.info["bucket_sets"] == 2
     small = _case(42, N, S, F, G, H, W, 3.5)
     y, g = _run(plan, *small, calls=2)
-    _check(y, g, *small, "small offsets (dense)")
+    _check(y, g, *small, "small offsets (dense)", dense_params=True)
     big = _case(43, N, S, F, G, H, W, 7.5)
     y, g = _run(plan, *big)                        # stale hint (3.5): the guard sends the call to the bucket-8 gather
     _check(y, g, *big, "large offsets (gather)")
@@ -108,5 +147,9 @@ def test_dense_bf16_through_the_layer():
     assert float((ya.float() - yb.float()).abs().max()) <= 2e-2 * scale
     gs = float(xa.grad.float().abs().max())
     assert float((xa.grad.float() - xb.grad.float()).abs().max()) <= 2e-2 * gs
-    # the parameter gradients do not go through the dense form: identical
-    assert torch.equal(exact.weights.grad, dense.weights.grad) and torch.equal(exact.mu1.grad, dense.mu1.grad)
+    # four units: the parameter gradients take the dense correlations as well (bf16 bar against the exact gather-dot)
+    for pa, pb in ((exact.weights, dense.weights), (exact.mu1, dense.mu1), (exact.mu2, dense.mu2), (exact.sigma, dense.sigma)):
+        if pa.grad is None:
+            continue
+        ps = float(pa.grad.abs().max())
+        assert float((pa.grad - pb.grad).abs().max()) <= 2e-2 * ps

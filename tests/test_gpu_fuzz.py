@@ -104,7 +104,8 @@ def test_random_configuration_dense_bf16(seed):
     if c["flags"]["forbid_positive_dim1"]: fl |= _capi.FLAG_FORBID_POSITIVE_DIM1
     sigma = c["sigma"] if c["sigma"] <= 0.8 else 0.5
     plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, number_units_ignore=c["ignore"], flags=fl, sigma_hint=sigma)
-    assert plan.info["gather_dense_bf16"] == 1
+    assert plan.info["gather_dense_bf16"] in (1, 2)
+    dense_params = plan.info["gather_dense_bf16"] == 2           # five or more units: dense parameter gradients, bf16 bar
     dev = lambda a: torch.from_numpy(a).cuda()
     sig = torch.full((1, S, G, F), sigma, device="cuda")
     for _ in range(2):                                  # kernel 17: the second round is the hinted (dense) one
@@ -123,4 +124,5 @@ def test_random_configuration_dense_bf16(seed):
     assert_parity(y.float().cpu().numpy(), want_y, tag + "y", rel=2e-2, floor=1e-2)
     assert_parity(got[0].float().cpu().numpy(), want["dx"], tag + "dx", rel=2e-2, floor=1e-2)
     for t, key in zip(got[1:], ("dw", "dmu1", "dmu2", "dsigma")):
-        assert_parity(t.cpu().numpy(), want[key], tag + key)
+        if dense_params: assert_parity(t.cpu().numpy(), want[key], tag + key, rel=2e-2, floor=1e-2)
+        else: assert_parity(t.cpu().numpy(), want[key], tag + key)

@@ -8,7 +8,7 @@ make -s -j8 >/dev/null
 mkdir -p ../../build/$name
 /opt/rocm/bin/hipcc -O3 -std=c++20 -fPIC --offload-arch=gfx950 -I../../include -I. -fvisibility=hidden -mllvm -pragma-unroll-threshold=1000000 $flags -c $src -o ../../build/$name/variant.o
 objs=""
-for o in dau_conv_api k_filters k_units k_direct k_gather_mfma k_gather_dot k_dense_bf16; do
+for o in dau_conv_api k_filters k_units k_direct k_gather_mfma k_gather_dot k_dense_bf16 k_dense_wgrad; do
   if [ "$o.hip" = "$src" ]; then objs="$objs ../../build/$name/variant.o"; else objs="$objs $o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/$name/libdau_conv_hip.so $objs
