@@ -61,6 +61,7 @@ WORKLOADS = {
     "small": dict(N=8, S=32, F=32, H=56, W=56, G=4, k=9, m=3.0, label="smoke-size N=8 C=32->32 HW=56 G=4"),
 }
 FP32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide; the 2:1-sparsity headline figure is not used)
 
 
 def parse_args():
@@ -332,10 +333,22 @@ def main():
     if dominant:
         traffic, traffic_note = measured_traffic(wl_key, args.io, dominant)
         ach = flops[dominant] / (kern[dominant]["avg_ms"] * 1e-3) / 1e12
-        roofline = dict(bound="mfma", kernel=dominant, achieved=round(ach, 2), peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / FP32_PEAK_TFLOPS, 4), traffic=traffic, traffic_unit="GB per pass",
+        peak, roof_note = FP32_PEAK_TFLOPS, None
+        dense_level = int(plan.info.get("gather_dense_bf16", 0)) if dense else 0
+        if (dense_level >= 1 and dominant != "gather_dot") or (dense_level == 2 and dominant == "gather_dot"):
+            # the pass ran in its densified form on the bf16 matrix cores: price the FLOPs that form executes (100 taps per
+            # (input, output) channel pair and pixel; 400 for the four parameter-gradient kinds) against the bf16 roof
+            taps = 400.0 if dominant == "gather_dot" else 100.0
+            ach = 2.0 * taps * N * H * W * S * F / (kern[dominant]["avg_ms"] * 1e-3) / 1e12
+            peak = BF16_PEAK_TFLOPS
+            roof_note = ("densified bf16 form: achieved = executed dense FLOPs (2*%d*N*H*W*S*F) / time against the dense bf16 "
+                         "MFMA peak; kernels[*].tflops stay algorithmic (gather form)" % int(taps))
+        roofline = dict(bound="mfma", kernel=dominant, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
+                        frac=round(ach / peak, 4), traffic=traffic, traffic_unit="GB per pass",
                         traffic_note=traffic_note, kernels=kern,
                         whole_step_tflops=round(32.0 * unit_px * args.steps / elapsed / 1e12, 2))
+        if roof_note:
+            roofline["note"] = roof_note
         # the BASELINE metric also asks for the HBM view: compulsory bytes of one fwd+bwd step (SURVEY.md 8d:
         # e*N*H*W*(3S+2F) + 7*4*S*G*F) over the step time, against the 8 TB/s roof -- ~1 %, the operator is compute bound
         e = 2 if args.io == "bf16" else 4
@@ -408,7 +421,7 @@ def main():
                               exchange="all_reduce(sum) of raw param-grad sums [4,S,G,F] = %d floats per step, async under the dx pass; finalize after"
                               % (4 * S * G * F)) if use_dist else None),
                    config=dict(workload=wl["label"] + (" [bf16 activations in HBM]" if args.io == "bf16" else "") +
-                               (" [gather-sum passes as densified bf16 MFMA GEMM]" if dense else "") +
+                               (" [gather-sum passes%s as densified bf16 MFMA GEMM]" % (" and parameter gradients" if dense and int(plan.info.get("gather_dense_bf16", 0)) == 2 else "") if dense else "") +
                                (" [one step captured into a HIP graph, replays timed]" if args.graph and not use_dist else "") +
                                ("" if backend == "nccl" else " [REHEARSAL: %s backend, ranks share GPUs]" % backend),
                                global_batch=N * world, parallelism="dp%d" % world,

@@ -108,8 +108,11 @@ enum {
     DAU_FLAG_DENSE_BF16 = 1 << 6,           /* with DAU_FLAG_IO_BF16: calls whose offsets lie within +-4 run their
                                                two gather-sum passes (y, dx) as a DENSIFIED implicit GEMM on the
                                                bf16 matrix cores (units scattered into a 10x10 kernel per channel
-                                               pair; taps and blurred activations rounded to bf16, fp32 sums).
-                                               Parameter gradients keep the exact fp32 path.                  */
+                                               pair; taps and blurred activations rounded to bf16, fp32 sums),
+                                               and -- from three units per channel on, rows of at most 60 pixels
+                                               -- their parameter gradients as dense cross-correlations on the
+                                               same matrix cores (filtered input and error rounded to bf16, fp32
+                                               sums).  Otherwise the exact fp32 path.                        */
     DAU_FLAG_DEFAULT = DAU_FLAG_USE_INTERPOLATION
 };
 
