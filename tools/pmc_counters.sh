@@ -15,8 +15,8 @@ tag = sys.argv[1]
 acc = {}
 for f in glob.glob("gpurun_out/pmcc_%s_*/**/*counter_collection.csv" % tag, recursive=True):
     for r in csv.DictReader(open(f)):
-        k = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0]
-        if not (k.startswith("dau::gather") or k.startswith("dau::dense_gather")):
+        k = re.sub(r"^void ", "", r["Kernel_Name"]).replace("(anonymous namespace)::", "").split("(")[0]
+        if not (k.startswith("dau::gather") or k.startswith("dau::dense_gather") or "wg_gemm" in k):
             continue
         d = acc.setdefault(k, {}).setdefault(r["Counter_Name"], [0.0, 0])
         d[0] += float(r["Counter_Value"]); d[1] += 1
