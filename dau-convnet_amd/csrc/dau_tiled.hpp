@@ -96,7 +96,8 @@ struct WgradConfig {
     Shape sh;
     int blur_k;
     int SB, FB, NC;       // 32-channel blocks of S and F, 16-image chunks of N
-    int HsT, WsT, WT;     // staged Xk plane (H+9 rows, WT+9 columns rounded up to 8) and error row (an instantiated length >= W)
+    int HsT, WsT, WT, nseg;   // staged Xk plane (H+9 rows, nseg*WT+9 columns rounded up to 8); a row is walked in nseg segments of WT
+                          // columns (an instantiated length)
     int splits;           // the image chunks are cut into `splits` ranges (partial sums per range)
     int Hp, Wp;           // plane of the intermediate fp32 copy (blur4_pack)
 };

@@ -14,9 +14,10 @@
 //
 // K runs over the IMAGES innermost, so that a displacement only changes the position and every matrix fragment is one
 // aligned KiB whatever d is:
-//   XkT[k][sb][nc][H+9][WsT][32 s][16 n] bf16   the four derivative-filtered copies of x, staged position (r, c) = image
+//   XkT[k][sb][nc][H+9][WsT][2][32 s][8 n] bf16 the four derivative-filtered copies of x, staged position (r, c) = image
 //                                               (r-4, c-4), zero outside the image (wg_stage_x from blur4_pack's fp32 copy)
-//   ET [fb][nc][H][WT][32 f][16 n]       bf16   the error (unit_testing edge rule applied), zero for columns W..WT-1 (WT = instantiated row length >= W)
+//   ET [fb][nc][H][WT'][32 f][16 n]      bf16   the error (unit_testing edge rule applied), zero for columns W..WT'-1 (WT' = whole
+//                                               row segments of an instantiated length)
 //   C  [split][k][10][10][SB*32][FB*32]  fp32   partial correlations of one range of image chunks
 // wg_gemm: workgroup = (32 input channels, kind k, row displacement oy, range of image chunks) x 8 waves = 8 blocks of 32
 // output channels; a wave keeps the ten column displacements ox as ten 32 x 32 accumulators and walks (image chunk, row,
@@ -50,7 +51,7 @@ WgLayout wg_layout(const WgradConfig& c) {
     size_t off = 0;
     l.xk_off = off;  off += round_up((size_t)((c.sh.N + 1) / 2) * c.SB * 32 * c.Hp * c.Wp * 32, 256);
     l.xkt_off = off; off += round_up((size_t)kNumK * c.SB * c.NC * c.HsT * c.WsT * 1024, 256);
-    l.et_off = off;  off += round_up((size_t)c.FB * c.NC * c.sh.H * c.WT * 1024 + (size_t)kWSlots * 1024, 256);   // + look-ahead past the end
+    l.et_off = off;  off += round_up((size_t)c.FB * c.NC * c.sh.H * c.nseg * c.WT * 1024 + (size_t)kWSlots * 1024, 256);   // + look-ahead past the end
     l.c_off = off;   off += round_up((size_t)c.splits * kNumK * kWD * kWD * c.SB * 32 * c.FB * 32 * 4, 256);
     l.total = off;
     return l;
@@ -103,8 +104,10 @@ __global__ void __launch_bounds__(512) wg_stage_x_kernel(const WgStageXArgs a) {
             o0[n] = (__bf16)lds[((n >> 1) * 32 + s) * 65 + p * 8 + k * 2 + (n & 1)];
             o1[n] = (__bf16)lds[((4 + (n >> 1)) * 32 + s) * 65 + p * 8 + k * 2 + (n & 1)];
         }
-        *reinterpret_cast<bf16x8*>(out + s * 16) = o0;
-        *reinterpret_cast<bf16x8*>(out + s * 16 + 8) = o1;
+        // fragment order [half of the images][32 s][8 n]: the 16 lanes ds_read_b128 serves per cycle then read 256 contiguous
+        // bytes (with [32 s][16 n] rows r and r+8 shared banks: half of the kernel's LDS cycles were two-way conflicts)
+        *reinterpret_cast<bf16x8*>(out + s * 8) = o0;
+        *reinterpret_cast<bf16x8*>(out + 256 + s * 8) = o1;
     }
 }
 
@@ -157,7 +160,7 @@ struct WgGemmArgs {
     const char* xkt;
     const char* et;
     float* c;
-    int SB, FB, NC, H, HsT, WsT, WT, splits, fgroups;
+    int SB, FB, NC, H, HsT, WsT, WT, nseg, rowf, splits, fgroups;   // WT: columns of a row segment, rowf: its Xk fragments (WT + 9)
     Guard guard;
 };
 
@@ -179,7 +182,7 @@ constexpr int kWDma = 10;          // global_load_lds instructions per wave and 
 
 template <int NSTEP>
 __global__ void __launch_bounds__(kWWaves * 64) wg_gemm_kernel(const WgGemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // two rows of WsT Xk fragments
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // two row segments of WT + 9 Xk fragments
     if (!guard_pass(a.guard)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -201,32 +204,35 @@ __global__ void __launch_bounds__(kWWaves * 64) wg_gemm_kernel(const WgGemmArgs 
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.0f;
 
-    const unsigned row_bytes = (unsigned)a.WsT * 1024;
-    const int rows = (nc1 - nc0) * a.H;
+    // a "row" of the walk = one segment of WT columns of an image row (rows of more than 60 pixels are cut into segments;
+    // a segment needs the WT + 9 staged columns from its first one)
+    const unsigned row_bytes = (unsigned)a.rowf * 1024;
+    const int per_chunk = a.H * a.nseg;
+    const int rows = (nc1 - nc0) * per_chunk;
     auto row_src = [&](int r) -> const char* {
-        const int nc = nc0 + r / a.H, y = r % a.H;
-        return a.xkt + (((((size_t)k * a.SB + sb) * a.NC + nc) * a.HsT + (y + oy)) * a.WsT) * 1024;
+        const int nc = nc0 + r / per_chunk, y = (r % per_chunk) / a.nseg, seg = r % a.nseg;
+        return a.xkt + (((((size_t)k * a.SB + sb) * a.NC + nc) * a.HsT + (y + oy)) * a.WsT + (size_t)seg * a.WT) * 1024;
     };
     auto issue_row = [&](int r, int buf) {
         const char* src = row_src(r);
 #pragma unroll
         for (int i = 0; i < kWDma; ++i) {
             int p = wave + i * kWWaves;
-            p = p < a.WsT ? p : a.WsT - 1;
+            p = p < a.rowf ? p : a.rowf - 1;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)p * 1024 + lane * 16),
                                              (lds_ptr_t)(smem + buf * row_bytes + p * 1024), 16, 0, 0);
         }
     };
-    // a lane's 16 bytes of a [32][16] fragment: row lane & 31, images 8 * (lane >> 5) .. + 7
+    // a lane's 16 bytes of a [32][16] fragment (E'): row lane & 31, images 8 * (lane >> 5) .. + 7
     const unsigned lfrag = (unsigned)((lane & 31) * 32 + (lane >> 5) * 16);
     if (rows > 0) issue_row(0, 0);
     for (int r = 0; r < rows; ++r) {
         const int buf = r & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                            // row r has landed; everybody is done with row r-1
-        const int nc = nc0 + r / a.H, y = r % a.H;
-        const char* arow = smem + buf * row_bytes + lfrag;
-        const char* erow = a.et + ((((size_t)fbc * a.NC + nc) * a.H + y) * a.WT) * 1024;     // wave-uniform
+        const int nc = nc0 + r / per_chunk, y = (r % per_chunk) / a.nseg, seg = r % a.nseg;
+        const char* arow = smem + buf * row_bytes + (unsigned)((lane >> 5) * 512 + (lane & 31) * 16);   // Xk fragments: [half][32][8]
+        const char* erow = a.et + ((((size_t)fbc * a.NC + nc) * a.H + y) * a.nseg + seg) * (size_t)a.WT * 1024;     // wave-uniform
         bf16x8 win[kWD];
         u32x4 eq[kWSlots];
         // E' of the first columns, THEN the next row's Xk (kWDma instructions): the waits of the first kWAhead columns step over them
@@ -307,14 +313,16 @@ bool dense_wgrad_configure(const Shape& sh, int blur_k, bool bf16, WgradConfig* 
     WgradConfig c{};
     c.sh = sh; c.blur_k = blur_k;
     c.SB = (sh.S + 31) / 32; c.FB = (sh.F + 31) / 32; c.NC = (sh.N + 15) / 16;
-    c.WT = 0;
-    for (int w : {14, 28, 30, 42, 56, 60})               // instantiated row lengths (wg_gemm_kernel<NSTEP>)
-        if (c.WT == 0 && sh.W <= w) c.WT = w;
-    if (c.WT == 0) return false;                          // rows of more than 60 pixels keep the exact gather-dot
+    // instantiated segment lengths (wg_gemm_kernel<NSTEP>): the fewest padded columns, then the fewest segments
+    c.WT = 0; c.nseg = 0;
+    for (int w : {14, 28, 30, 42, 56, 60}) {
+        const int n = (sh.W + w - 1) / w;
+        if (c.WT == 0 || n * w < c.nseg * c.WT || (n * w == c.nseg * c.WT && n < c.nseg)) { c.WT = w; c.nseg = n; }
+    }
     c.HsT = sh.H + kWD - 1;
-    c.WsT = (int)round_up((size_t)c.WT + kWD - 1, 8);
+    c.WsT = (int)round_up((size_t)c.nseg * c.WT + kWD - 1, 8);
     c.Hp = sh.H; c.Wp = (sh.W + 7) / 8 * 8;
-    if ((size_t)2 * c.WsT * 1024 > 160 * 1024 || c.WsT > kWDma * kWWaves || c.WT > kWMaxSteps) return false;   // two rows of fragments in LDS
+    if (c.WT + kWD - 1 > kWDma * kWWaves || c.WT > kWMaxSteps) return false;   // two row segments of WT + 9 fragments in LDS
     if (!blur4_pack_fits(blur_k, c.Hp, c.Wp)) return false;
     const int fgroups = (c.FB + kWWaves - 1) / kWWaves;
     const int base = c.SB * fgroups * kWD * kNumK;
@@ -350,18 +358,18 @@ void dense_wgrad_run(hipStream_t st, const WgradConfig& c, const float* x, const
     {
         WgStageEArgs a{};
         a.dy = reinterpret_cast<const unsigned short*>(dy); a.et = reinterpret_cast<__bf16*>(ws + l.et_off);
-        a.N = s.N; a.F = s.F; a.FB = c.FB; a.NC = c.NC; a.H = s.H; a.W = s.W; a.WT = c.WT; a.drop_col = drop_col; a.drop_row = drop_row;
+        a.N = s.N; a.F = s.F; a.FB = c.FB; a.NC = c.NC; a.H = s.H; a.W = s.W; a.WT = c.nseg * c.WT; a.drop_col = drop_col; a.drop_row = drop_row;
         a.guard = guard;
-        hipLaunchKernelGGL(wg_stage_e_kernel, dim3(c.FB * c.NC * s.H * ((c.WT + 31) / 32)), dim3(512), 0, st, a);
+        hipLaunchKernelGGL(wg_stage_e_kernel, dim3(c.FB * c.NC * s.H * ((c.nseg * c.WT + 31) / 32)), dim3(512), 0, st, a);
     }
     {
         WgGemmArgs a{};
         a.xkt = ws + l.xkt_off; a.et = ws + l.et_off; a.c = reinterpret_cast<float*>(ws + l.c_off);
-        a.SB = c.SB; a.FB = c.FB; a.NC = c.NC; a.H = s.H; a.HsT = c.HsT; a.WsT = c.WsT; a.WT = c.WT; a.splits = c.splits;
+        a.SB = c.SB; a.FB = c.FB; a.NC = c.NC; a.H = s.H; a.HsT = c.HsT; a.WsT = c.WsT; a.WT = c.WT; a.nseg = c.nseg; a.rowf = c.WT + kWD - 1; a.splits = c.splits;
         a.fgroups = (c.FB + kWWaves - 1) / kWWaves; a.guard = guard;
         const int grid = c.SB * a.fgroups * kWD * kNumK * c.splits;
         void* args[] = {&a};
-        (void)hipLaunchKernel(wg_gemm_for(c.WT), dim3(grid), dim3(kWWaves * 64), args, (size_t)2 * c.WsT * 1024, st);
+        (void)hipLaunchKernel(wg_gemm_for(c.WT), dim3(grid), dim3(kWWaves * 64), args, (size_t)2 * (c.WT + kWD - 1) * 1024, st);
     }
     {
         const long units = (long)s.S * s.G * s.F;

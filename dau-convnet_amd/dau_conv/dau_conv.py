@@ -322,7 +322,7 @@ class DAUConv2d(nn.Module):
     (`dau_conv.check_pending_offsets()` flushes); True: wait for every call and raise at once, as the reference does;
     False: never read the result back.  `dense_bf16=True` (bfloat16 inputs only): calls whose offsets lie within +-4 run
     their forward and input-gradient passes as a densified bf16 matrix-core GEMM (DAU_FLAG_DENSE_BF16: taps and blurred
-    activations rounded to bf16, fp32 sums) and, from three units per channel on (rows of at most 60 pixels), their
+    activations rounded to bf16, fp32 sums) and, from three units per channel on, their
     parameter gradients as dense cross-correlations on the same cores -- the whole step about 2x faster than the exact
     path at six units, at the bf16 tolerance.
     """

@@ -109,8 +109,7 @@ enum {
                                                two gather-sum passes (y, dx) as a DENSIFIED implicit GEMM on the
                                                bf16 matrix cores (units scattered into a 10x10 kernel per channel
                                                pair; taps and blurred activations rounded to bf16, fp32 sums),
-                                               and -- from three units per channel on, rows of at most 60 pixels
-                                               -- their parameter gradients as dense cross-correlations on the
+                                               and -- from three units per channel on -- their parameter gradients as dense cross-correlations on the
                                                same matrix cores (filtered input and error rounded to bf16, fp32
                                                sums).  Otherwise the exact fp32 path.                        */
     DAU_FLAG_DEFAULT = DAU_FLAG_USE_INTERPOLATION
@@ -169,7 +168,7 @@ typedef struct dau_conv_plan_info {
     int32_t gather_windows;    /* tiled gather-sum: offset-window passes (1 for kernels <= 33)    */
     int32_t bucket_sets;       /* kernel sets a call can choose from (1: static bucket only)      */
     int32_t gather_dense_bf16; /* 1: the bucket-4 gather-sum passes use the densified bf16 GEMM;
-                                  2: the parameter gradients too (three or more units, rows <= 60) */
+                                  2: the parameter gradients too (three or more units)          */
     int32_t batch_slab_gather; /* images staged and gathered at a time by the y / dx passes and   */
     int32_t batch_slab_dot;    /* by the parameter-gradient pass of the static bucket (= batch
                                   unless the staged copy would exceed the workspace budget)      */

@@ -65,8 +65,8 @@ def test_dense_bf16_gather_against_oracle(shape):
     mu1.flat[0] = 3.99; mu2.flat[0] = -3.99; mu1.flat[1] = -4.0; mu2.flat[1] = 4.0       # the corners of the 10 x 10 kernel
     flags = _capi.FLAG_USE_INTERPOLATION | _capi.FLAG_IO_BF16 | _capi.FLAG_DENSE_BF16
     plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=flags)
-    # three or more units (and rows of at most 60 pixels): the parameter gradients take the dense form too
-    assert plan.info["gather_dense_bf16"] == (2 if G >= 3 and W <= 60 else 1)
+    # three or more units: the parameter gradients take the dense form too
+    assert plan.info["gather_dense_bf16"] == (2 if G >= 3 else 1)
     y, g = _run(plan, xb, dyb, w, mu1, mu2)
     _check(y, g, xb, dyb, w, mu1, mu2, "dense", dense_params=plan.info["gather_dense_bf16"] == 2)
 
@@ -78,6 +78,10 @@ def test_dense_bf16_gather_against_oracle(shape):
     dict(N=2, S=33, F=290, G=2, H=28, W=28),      # ten 32-channel blocks of F = two workgroup groups; forced for two units
     dict(N=36, S=8, F=8, G=1, H=12, W=60),        # three image chunks (split), the widest row the form takes
     dict(N=4, S=40, F=24, G=9, H=14, W=31),
+    # rows of more than 60 pixels are walked in segments of an instantiated length
+    dict(N=2, S=8, F=8, G=3, H=6, W=112),         # 2 x 56
+    dict(N=2, S=8, F=40, G=4, H=5, W=64),         # 5 x 14 (70 columns)
+    dict(N=3, S=5, F=8, G=2, H=4, W=130),         # 5 x 28 (140)
 ])
 @pytest.mark.parametrize("unit_testing", [False, True])
 def test_dense_parameter_gradients_against_oracle(shape, unit_testing, monkeypatch):
