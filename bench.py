@@ -24,6 +24,7 @@ Extra objects in the line:
 import argparse
 import hashlib
 import json
+import math
 import os
 import socket
 import subprocess
@@ -81,6 +82,10 @@ def parse_args():
     ap.add_argument("--algo", type=int, default=0, help="0 auto, 1 direct, 2 tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-layer", action="store_true", help="skip the layer-level (DAUConv2d + autograd) timing")
+    ap.add_argument("--offsets", default="uniform", metavar="uniform|grid[:JITTER]",
+                    help="offset distribution: uniform = mu ~ U(-m, m) per unit (the reference tests' and BASELINE's synthetic "
+                         "data; the worst case for the binned large-offset kernels), grid = the units of every channel pair on "
+                         "the regular grid the reference layer initialises them on (DAUGridMean) + U(-JITTER, JITTER), default 1")
     ap.add_argument("--check", type=int, default=0, metavar="IMAGES",
                     help="parity gate before timing: y and dx of the first IMAGES images against the CPU oracle")
     return ap.parse_args()
@@ -233,6 +238,20 @@ def main():
     lim = k // 2 - 0.01
     mu1 = ((torch.rand((1, S, G, F), device=dev, generator=pgen) * 2 - 1) * m).clamp_(-lim, lim)
     mu2 = ((torch.rand((1, S, G, F), device=dev, generator=pgen) * 2 - 1) * m).clamp_(-lim, lim)
+    if args.offsets.startswith("grid"):
+        # the live units on a near-square grid spanning +-(m - 1), as DAUGridMean places them (dau_conv.py:24-62 of the
+        # reference), every (input, output) channel pair jittered on its own
+        from dau_conv import DAUGridMean
+        jitter = float(args.offsets.split(":")[1]) if ":" in args.offsets else 1.0
+        gx = int(math.ceil(math.sqrt(G_live))); gy = (G_live + gx - 1) // gx
+        ax = torch.tensor(DAUGridMean((gy, gx), max(m - 1.0, 0.0)).legacy_values(gx), dtype=torch.float32, device=dev)
+        ay = torch.tensor(DAUGridMean((gy, gx), max(m - 1.0, 0.0)).legacy_values(gy), dtype=torch.float32, device=dev)
+        g = torch.arange(G, device=dev)
+        live = (g < G_live).float()
+        base1 = (ax[(g % gx).clamp(max=gx - 1)] * live).view(1, 1, G, 1)
+        base2 = (ay[(g // gx).clamp(max=gy - 1)] * live).view(1, 1, G, 1)
+        mu1 = (base1 + (torch.rand((1, S, G, F), device=dev, generator=pgen) * 2 - 1) * jitter).clamp_(-lim, lim)
+        mu2 = (base2 + (torch.rand((1, S, G, F), device=dev, generator=pgen) * 2 - 1) * jitter).clamp_(-lim, lim)
     sigma = torch.full((1, S, G, F), 0.5, device=dev)
 
     if args.io == "bf16":
@@ -421,6 +440,7 @@ def main():
                               exchange="all_reduce(sum) of raw param-grad sums [4,S,G,F] = %d floats per step, async under the dx pass; finalize after"
                               % (4 * S * G * F)) if use_dist else None),
                    config=dict(workload=wl["label"] + (" [bf16 activations in HBM]" if args.io == "bf16" else "") +
+                               (" [offsets: %s instead of U(-m,m)]" % args.offsets if args.offsets != "uniform" else "") +
                                (" [gather-sum passes%s as densified bf16 MFMA GEMM]" % (" and parameter gradients" if dense and int(plan.info.get("gather_dense_bf16", 0)) == 2 else "") if dense else "") +
                                (" [one step captured into a HIP graph, replays timed]" if args.graph and not use_dist else "") +
                                ("" if backend == "nccl" else " [REHEARSAL: %s backend, ranks share GPUs]" % backend),
