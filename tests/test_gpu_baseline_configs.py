@@ -117,6 +117,34 @@ def test_c4_seg_scale_large_offsets(static_bucket):
     assert float(np.abs(got["dw"][:, :, G - 1]).max()) == 0.0
 
 
+@pytest.mark.parametrize("layout", ["grid", "one_window", "one_point"])
+def test_large_offsets_clustered_units(layout):
+    """The window passes with CLUSTERED offsets (a layer keeps its units near the grid DAUGridMean places them on; the
+    uniform offsets of the other tests spread them evenly): all nine units on a 3 x 3 grid +- 1 pixel, all nine inside ONE
+    offset window (every slot pair of that window full, the other windows empty), and all nine at the same point."""
+    from dau_conv import _capi
+    N, S, F, G, H, W, k = 2, 5, 40, 9, 40, 52, 65
+    rs = np.random.RandomState(77)
+    x = rs.rand(N, S, H, W).astype(np.float32)
+    dy = rs.randn(N, F, H, W).astype(np.float32)
+    w = (rs.randn(1, S, G, F) * 0.1).astype(np.float32)
+    g = np.arange(G)
+    if layout == "grid":
+        c1 = np.array([-11.0, 0.0, 11.0])[g % 3]; c2 = np.array([-11.0, 0.0, 11.0])[g // 3]; j = 1.0
+    elif layout == "one_window":
+        c1 = np.full(G, -9.0); c2 = np.full(G, 9.0); j = 7.9
+    else:
+        c1 = np.full(G, 12.3); c2 = np.full(G, -16.6); j = 0.0
+    mu1 = (c1.reshape(1, 1, G, 1) + rs.uniform(-j, j, (1, S, G, F))).astype(np.float32)
+    mu2 = (c2.reshape(1, 1, G, 1) + rs.uniform(-j, j, (1, S, G, F))).astype(np.float32)
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, sigma_hint=0.5)
+    got = _run(plan, x, dy, w, mu1, mu2, calls=2)        # second call: bucket 18 (2 x 2 windows of radius 9)
+    _check_all(got, x, dy, w, mu1, mu2, "clustered/" + layout)
+    static = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, sigma_hint=0.5, flags=_capi.FLAG_USE_INTERPOLATION | _capi.FLAG_STATIC_BUCKET)
+    got = _run(static, x, dy, w, mu1, mu2)               # bucket 32: 4 x 4 gather-dot windows, 2 x 2 gather-sum windows
+    _check_all(got, x, dy, w, mu1, mu2, "clustered/" + layout + "/static")
+
+
 @pytest.mark.parametrize("shape", [
     # dau_conv_test.py:433,436,449,455: kernel 17 declared, offsets within +-3
     dict(N=16, S=32, F=32, G=4, H=32, W=32, k=17, m=3.0),
