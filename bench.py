@@ -88,6 +88,13 @@ def parse_args():
                          "the regular grid the reference layer initialises them on (DAUGridMean) + U(-JITTER, JITTER), default 1")
     ap.add_argument("--check", type=int, default=0, metavar="IMAGES",
                     help="parity gate before timing: y and dx of the first IMAGES images against the CPU oracle")
+    ap.add_argument("--check-params", type=int, default=0, metavar="CHANNELS",
+                    help="with --check: also dw, dmu1, dmu2, dsigma of the first CHANNELS output channels (sums over the WHOLE "
+                         "batch: the oracle runs all N images on that slice of the output channels)")
+    ap.add_argument("--steady-seconds", type=float, default=8.0,
+                    help="after the timed steps, keep stepping for about this long (at most 200 steps) and report the mean step "
+                         "time of that run as roofline.steady_state_ms: the kernels are power limited and the headline's few "
+                         "steps are over before the chip has warmed up (0: skip)")
     return ap.parse_args()
 
 
@@ -263,6 +270,8 @@ def main():
     from dau_conv.distributed import OverlappedBackward
     exchange = OverlappedBackward((1, S, G, F), dev) if use_dist else None
 
+    last_grads = [None]
+
     def step():
         y = plan.forward(x, w, mu1, mu2, sigma)
         if use_dist:
@@ -273,7 +282,8 @@ def main():
                               lambda sums: plan.finalize_param_grads(sums, w))
             exchange.wait()
         else:
-            dx = plan.backward(x, dy, w, mu1, mu2, sigma)[0]
+            last_grads[0] = plan.backward(x, dy, w, mu1, mu2, sigma)
+            dx = last_grads[0][0]
         return y, dx
 
     def fence():
@@ -298,6 +308,20 @@ def main():
             return float((np.abs(got - want) - (rel * np.abs(want) + floor * np.abs(want).max())).max())
         vy, vdx = viol(y[:nchk].float().cpu().numpy(), want_y), viol(dx[:nchk].float().cpu().numpy(), want_dx)
         parity = dict(images=nchk, y_violation=vy, dx_violation=vdx, ok=bool(vy <= 0 and vdx <= 0), rel=rel, floor=floor)
+        if args.check_params > 0 and not use_dist:
+            # the parameter gradients are sums over the batch: the oracle takes all N images on a slice of the output channels
+            fs = min(F, args.check_params)
+            dense_params = bool(args.dense and int(plan.info.get("gather_dense_bf16", 0)) == 2)
+            prel, pfloor = (2e-2, 4e-3) if dense_params else (1e-4, 1e-6)
+            want = orc.backward(x.float().cpu().numpy(), dy[:, :fs].float().cpu().numpy(), wn[..., :fs].copy(), m1n[..., :fs].copy(),
+                                m2n[..., :fs].copy(), 0.5, ignore=ignore, need=("dw", "dmu1", "dmu2", "dsigma"))
+            pv = {}
+            for i, key in enumerate(("dw", "dmu1", "dmu2", "dsigma")):
+                got = np.asarray(last_grads[0][i + 1][..., :fs].cpu().numpy(), np.float64)
+                wv = np.asarray(want[key], np.float64)
+                pv[key] = float((np.abs(got - wv) - (prel * np.abs(wv) + pfloor * np.abs(wv).max())).max())
+            parity.update(param_channels=fs, param_violation=pv, param_rel=prel, param_floor=pfloor)
+            parity["ok"] = bool(parity["ok"] and all(v <= 0 for v in pv.values()))
         if not parity["ok"]:
             raise SystemExit("bench.py --check: the HIP path differs from the oracle: %s" % parity)
 
@@ -334,6 +358,23 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # thermal steady state: NOT part of the headline (value / ms_per_step come from exactly --steps steps above); the same
+    # step repeated for several seconds, timed as a whole
+    steady = None
+    if args.steady_seconds > 0 and not args.graph:
+        per = elapsed / args.steps
+        nsteady = int(max(4, min(200, math.ceil(args.steady_seconds / per))))
+        fence()
+        s0 = time.perf_counter()
+        for _ in range(nsteady):
+            step()
+        fence()
+        sel = time.perf_counter() - s0
+        if use_dist:
+            t = torch.tensor([sel], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            sel = float(t.item())
+        steady = dict(ms=round(sel / nsteady * 1e3, 3), steps=nsteady)
 
     samples = float(N) * world * H * W * args.steps
     value = samples / elapsed / 1e9
@@ -368,6 +409,11 @@ def main():
                         whole_step_tflops=round(32.0 * unit_px * args.steps / elapsed / 1e12, 2))
         if roof_note:
             roofline["note"] = roof_note
+        if steady:
+            roofline["steady_state_ms"] = steady["ms"]
+            roofline["steady_state_steps"] = steady["steps"]
+            roofline["steady_state_note"] = ("mean step time of %d further steps run right after the timed region (not part of "
+                                             "value / ms_per_step): the kernels are power limited, this is the warmed-up chip" % steady["steps"])
         # the BASELINE metric also asks for the HBM view: compulsory bytes of one fwd+bwd step (SURVEY.md 8d:
         # e*N*H*W*(3S+2F) + 7*4*S*G*F) over the step time, against the 8 TB/s roof -- ~1 %, the operator is compute bound
         e = 2 if args.io == "bf16" else 4
@@ -411,10 +457,10 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import dau_oracle as orc
-        # bounded sample (~10-30 s of CPU work at the ~7e10 FLOP/s the oracle reaches on the box's cores): whole images of
-        # the same batch; where one image is already too much (512 x 512 maps), the first output channels only -- the
-        # work is linear in the output channels, and the rate is scaled back to all F of them
-        budget = 1.6e12
+        # bounded sample (about 8 s of CPU work at the ~6e10 FLOP/s the oracle reaches on the box's cores, so that the run
+        # stays GPU-dominated): whole images of the same batch; where one image is already too much (512 x 512 maps), the
+        # first output channels only -- the work is linear in the output channels, and the rate is scaled back to all F
+        budget = 0.45e12
         per_image = 32.0 * G_live * H * W * S * F
         ncpu = int(max(1, min(N, 32, budget // per_image)))
         fcpu = F if per_image <= budget else int(max(8, min(F, budget // (per_image / F))))

@@ -5,6 +5,20 @@
 #include <cstdint>
 #include "dau_conv.h"
 
+// Tuning knobs.  The shipped library's behaviour is fully determined by dau_conv_desc (plus DAU_WORKSPACE_BUDGET_GB): the
+// environment variables that pin a kernel variant, a chunking or a staging tile for same-box A/B runs and for the variant
+// tests exist only in the TUNING build (-DDAU_TUNING: libdau_conv_hip_tuning.so, `make tuning`), where these macros read the
+// environment at plan creation.  In the release build they are their defaults and the names are not in the binary
+// (tests/test_capi_symbols.py checks that).
+#ifdef DAU_TUNING
+#include <cstdlib>
+#define DAU_TUNE_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#define DAU_TUNE_SET(name) (getenv(name) != nullptr)
+#else
+#define DAU_TUNE_INT(name, dflt) (dflt)
+#define DAU_TUNE_SET(name) (false)
+#endif
+
 namespace dau {
 
 // bfloat16 I/O (DAU_FLAG_IO_BF16): activations are stored as the upper 16 bits of an fp32
@@ -98,6 +112,13 @@ struct Status {
     unsigned int pad[2];
 };
 
+// Pinned host mirror of a plan (written by the last workgroup of prepare_units_kernel, read by dau_conv_last_status and as
+// the next call's offset-bucket hint): the most recent completed call's status, and the sticky record of bad ones.
+struct HostStatus {
+    unsigned int max_abs_mu_bits, nan_seen, valid, pad0;      // most recent completed call
+    unsigned int bad_max_abs_mu_bits, bad_nan_seen, pad1[2];  // worst status since the host last reported one (sticky)
+};
+
 // Offset-bucket guard of a launch.  The bucket a call needs depends on max|mu|, which only the device knows when the
 // kernels are enqueued (prepare_units_kernel leaves it in the status block).  The host enqueues the kernel sets of up to
 // two candidate buckets; every kernel of a set starts with guard_pass() and returns at once unless the actual max|mu|
@@ -132,9 +153,7 @@ void launch_synth_filters_compact(hipStream_t st, const float* sigma_dev, int k,
 // host_status (may be null): pinned host copy of the status block, written by the last workgroup to finish
 void launch_prepare_units(hipStream_t st, const float* w, const float* mu1, const float* mu2, Shape sh,
                           int ignore, int flags, int bucket, bool transposed_negated, UnitRef* table,
-                          Status* status, Status* host_status);
-void launch_unit_table_export(hipStream_t st, const float* mu1, const float* mu2, long units, int flags,
-                              int32_t* offsets, float* factors);
+                          Status* status, HostStatus* host_status);
 void launch_finalize_grads(hipStream_t st, const float* r4, const float* w, Shape sh, int ignore, float lr,
                            int need_mask, bool single_dim, float* dw, float* dmu1, float* dmu2, float* dsigma);
 // k_direct.hip  (DAU_ALGO_DIRECT: plain kernels, any shape)

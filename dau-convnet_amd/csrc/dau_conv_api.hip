@@ -8,7 +8,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <utility>
@@ -83,7 +85,8 @@ struct BucketSet {
     TiledDotConfig tiled_dot;
     // DAU_FLAG_DENSE_BF16, bucket 4 only: the gather-sum passes run as a densified bf16 implicit GEMM (k_dense_bf16.hip)
     bool dense_ok = false;
-    // ... and, from five units on, the parameter gradients as dense correlations on the same matrix cores (k_dense_wgrad.hip)
+    // ... and, from three units on (DAU_FLAG_DENSE_WGRAD_NEVER / _ALWAYS: never / from one unit on), the parameter gradients as
+    // dense correlations on the same matrix cores (k_dense_wgrad.hip)
     bool wgrad_ok = false;
     WgradConfig wgrad;
     DenseConfig dense_fwd, dense_dx;
@@ -106,11 +109,13 @@ struct dau_conv_plan {
     int nsets = 0;             // bucket sets, ascending; sets[nsets - 1] is the static bucket
     BucketSet sets[kNumBuckets];
     bool dynamic = false;      // pick the set from the actual offsets (tiled kernels only)
-    // pinned host mirror of the status block of the most recent completed call: {max|mu| bits, nan, valid, -}.  It is
-    // the offset-bucket hint of the next call and what dau_conv_last_status reports; a stale or torn value only costs
-    // speed, never correctness (the device-side guards decide which set really runs).
-    Status* host_status = nullptr;
-    mutable bool attrs_set = false;   // dynamic-LDS limits raised on this device (first call)
+    // pinned host mirror (HostStatus, dau_common.hpp): the status of the most recent completed call -- the offset-bucket hint
+    // of the next call; a stale or torn value only costs speed, never correctness (the device-side guards decide which set
+    // really runs) -- and the STICKY record of the worst status any completed call has left since the last report.
+    HostStatus* host_status = nullptr;
+    // dynamic-LDS limits raised on these devices (bit d: done on device d; the first call on a device does it behind the lock)
+    mutable std::atomic<unsigned long long> attrs_devices{0};
+    mutable std::mutex attrs_mutex;
     const BucketSet& top() const { return sets[nsets - 1]; }
     long units() const { return (long)sh.S * sh.G * sh.F; }
     // optional benchmark timing (dau_conv_profile_begin/_end); mutable because the passes take a const plan
@@ -161,34 +166,51 @@ struct Candidate {
 void clear_host_status(const dau_conv_plan* p) {
     if (!p->host_status) return;
     volatile unsigned* h = reinterpret_cast<volatile unsigned*>(p->host_status);
-    h[2] = 0u; h[1] = 0u; h[0] = 0u;
+    h[2] = 0u; h[1] = 0u; h[0] = 0u; h[4] = 0u; h[5] = 0u;
 }
 
 // pass_kind: 0 = gather-sum (needs fwd_ok), 1 = gather-dot (needs dot_ok)
-int pick_candidates(const dau_conv_plan* p, const Status* dev_status, int pass_kind, Candidate out[2]) {
+// A plan with DAU_FLAG_DENSE_BF16 has one member whose ARITHMETIC differs (bucket 4: bf16 products): that member is enqueued,
+// guarded by (-1, 4], on every call, hint or no hint, so that which arithmetic a call gets depends on its own offsets only.
+constexpr int kMaxCandidates = 3;
+int pick_candidates(const dau_conv_plan* p, const Status* dev_status, int pass_kind, Candidate out[kMaxCandidates]) {
     const BucketSet* top = &p->top();
     out[0] = Candidate{top, Guard{nullptr, 0.0f, 0.0f}};
-    if (!p->dynamic || !p->host_status || p->nsets < 2) return 1;
-    const volatile unsigned* h = reinterpret_cast<const volatile unsigned*>(p->host_status);
-    if (h[2] != 1u || h[1] != 0u) return 1;
-    float mx;
-    const unsigned bits = h[0];
-    std::memcpy(&mx, &bits, sizeof(float));
-    if (!(mx >= 0.0f)) return 1;
-    for (int i = 0; i + 1 < p->nsets; ++i) {
-        const BucketSet& b = p->sets[i];
-        if (mx > (float)b.bucket || !(pass_kind == 0 ? b.fwd_ok : b.dot_ok)) continue;
-        out[0] = Candidate{&b, Guard{dev_status, -1.0f, (float)b.bucket}};
-        out[1] = Candidate{top, Guard{dev_status, (float)b.bucket, INFINITY}};
-        return 2;
+    if (!p->dynamic || p->nsets < 2) return 1;
+    const BucketSet* dense = (pass_kind == 0 ? p->sets[0].dense_ok : p->sets[0].wgrad_ok) ? &p->sets[0] : nullptr;
+    const BucketSet* hinted = nullptr;
+    if (p->host_status) {
+        const volatile unsigned* h = reinterpret_cast<const volatile unsigned*>(p->host_status);
+        float mx = -1.0f;
+        if (h[2] == 1u && h[1] == 0u) {
+            const unsigned bits = h[0];
+            std::memcpy(&mx, &bits, sizeof(float));
+        }
+        if (mx >= 0.0f)
+            for (int i = 0; i + 1 < p->nsets && !hinted; ++i) {
+                const BucketSet& b = p->sets[i];
+                if (mx <= (float)b.bucket && (pass_kind == 0 ? b.fwd_ok : b.dot_ok)) hinted = &b;
+            }
     }
-    return 1;
+    int n = 0;
+    float lo = -1.0f;
+    if (dense && hinted != dense) { out[n++] = Candidate{dense, Guard{dev_status, lo, (float)dense->bucket}}; lo = (float)dense->bucket; }
+    if (hinted) { out[n++] = Candidate{hinted, Guard{dev_status, lo, (float)hinted->bucket}}; lo = (float)hinted->bucket; }
+    if (n == 0) return 1;                                    // no hint, nothing dense: the static set, unguarded
+    out[n++] = Candidate{top, Guard{dev_status, lo, INFINITY}};
+    return n;
 }
 
-// first call of a plan: raise the dynamic-LDS limit of every kernel its sets can launch (per device, hence not at plan
-// creation, which must also work without a device)
+// first call of a plan on a device: raise the dynamic-LDS limit of every kernel its sets can launch (function attributes are
+// per device, hence not at plan creation, which must also work without a device).  Plans are shared between threads (the
+// TF plan cache hands one plan to every Compute of a shape): the first call on a device does this behind the plan's lock.
 int ensure_attrs(const dau_conv_plan* p) {
-    if (p->attrs_set) return DAU_OK;
+    int dev = 0;
+    DAU_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (p->attrs_devices.load(std::memory_order_acquire) & bit) return DAU_OK;
+    std::lock_guard<std::mutex> lock(p->attrs_mutex);
+    if (p->attrs_devices.load(std::memory_order_relaxed) & bit) return DAU_OK;
     (void)hipGetLastError();
     for (int i = 0; i < p->nsets; ++i) {
         if (p->sets[i].fwd_ok) { tiled_gather_init(p->sets[i].tiled_fwd); tiled_gather_init(p->sets[i].tiled_dx); }
@@ -200,7 +222,7 @@ int ensure_attrs(const dau_conv_plan* p) {
             return fail(DAU_INTERNAL, "raising the dynamic-LDS limit of the bucket-%d kernels failed: %s", p->sets[i].bucket,
                         hipGetErrorString(e));
     }
-    p->attrs_set = true;
+    p->attrs_devices.fetch_or(bit, std::memory_order_release);
     return DAU_OK;
 }
 
@@ -292,6 +314,8 @@ const char* dau_conv_build_id(void) { return DAU_BUILD_ID; }
 
 const char* dau_conv_last_error(void) { return g_last_error.c_str(); }
 
+int dau_conv_filter_support(float sigma) { return 2 * (int)std::ceil(5.0f * sigma) + 1; }   // base_dau_conv_layer.cpp:146
+
 int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
     if (!desc || !plan_out) return fail(DAU_INVALID_ARGUMENT, "null argument");
     if (desc->struct_size != (int32_t)sizeof(dau_conv_desc))
@@ -318,7 +342,7 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
                     "DAUConv: offsets larger than the 32 px the kernels stage (set max_kernel_size <= 65)");
     if (!(desc->sigma_hint > 0.0f))  // DAU_CHECK(sigma > 0) base_dau_conv_layer.cpp:143
         return fail(DAU_FAILED_PRECONDITION, "Must use sigma > 0 - initialize it with appropriate value");
-    const int blur_k = 2 * (int)std::ceil(5.0f * desc->sigma_hint) + 1;  // base_dau_conv_layer.cpp:146
+    const int blur_k = dau_conv_filter_support(desc->sigma_hint);
     if (blur_k > kMaxBlurSupport)
         return fail(DAU_INVALID_ARGUMENT, "sigma %.3f needs a %dx%d prefilter; at most %dx%d is supported", desc->sigma_hint,
                     blur_k, blur_k, kMaxBlurSupport, kMaxBlurSupport);
@@ -375,9 +399,8 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
         {
             // dense parameter gradients: the bf16 layer's bucket-4 set, whole batch in one slab, three or more units (its cost
             // does not depend on the unit count: 15.3 ms at the north-star size against 16.0 ms for the exact gather-dot of a
-            // four-unit block, 9.7 ms of two units); DAU_DENSE_WGRAD=0 / 1: never / from one unit on (A/B and tests)
-            const char* wenv = getenv("DAU_DENSE_WGRAD");
-            const int min_units = wenv ? (atoi(wenv) == 0 ? 1 << 30 : 1) : 3;
+            // four-unit block, 9.7 ms of two units); DAU_FLAG_DENSE_WGRAD_NEVER / _ALWAYS: never / from one unit on
+            const int min_units = (desc->flags & DAU_FLAG_DENSE_WGRAD_NEVER) ? 1 << 30 : (desc->flags & DAU_FLAG_DENSE_WGRAD_ALWAYS) ? 1 : 3;
             bs.wgrad_ok = want_dense && bf16 && b == 4 && bs.dense_ok && bs.dot_ok && bs.slab_dot == s.N && s.G >= min_units &&
                           dense_wgrad_configure(s, blur_k, bf16, &bs.wgrad) &&
                           (double)dense_wgrad_workspace_bytes(bs.wgrad) <= budget_bytes;
@@ -386,6 +409,11 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
     if ((desc->flags & DAU_FLAG_DENSE_BF16) && !bf16) {
         delete p;
         return fail(DAU_INVALID_ARGUMENT, "DAU_FLAG_DENSE_BF16 needs DAU_FLAG_IO_BF16 (it is the bf16 layer's gather-sum)");
+    }
+    if ((desc->flags & (DAU_FLAG_DENSE_WGRAD_NEVER | DAU_FLAG_DENSE_WGRAD_ALWAYS)) &&
+        (!(desc->flags & DAU_FLAG_DENSE_BF16) || (desc->flags & DAU_FLAG_DENSE_WGRAD_NEVER && desc->flags & DAU_FLAG_DENSE_WGRAD_ALWAYS))) {
+        delete p;
+        return fail(DAU_INVALID_ARGUMENT, "DAU_FLAG_DENSE_WGRAD_NEVER / _ALWAYS qualify DAU_FLAG_DENSE_BF16 and exclude each other");
     }
     const bool fwd_ok = p->top().fwd_ok, dot_ok = p->top().dot_ok;
     if (bf16 && (desc->algo == DAU_ALGO_DIRECT || !(fwd_ok && dot_ok))) {
@@ -398,16 +426,15 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
     }
     p->algo_fwd = (desc->algo != DAU_ALGO_DIRECT && fwd_ok) ? DAU_ALGO_TILED : DAU_ALGO_DIRECT;
     p->algo_bwd = (desc->algo != DAU_ALGO_DIRECT && dot_ok) ? DAU_ALGO_TILED : DAU_ALGO_DIRECT;
-    // dynamic bucket selection: tiled kernels, more than one bucket, not switched off (flag, or DAU_DYNAMIC_BUCKET=0 in
-    // the environment at plan creation: A/B timing).  The pinned status mirror needs a device; without one (header-only
-    // checks on a CPU box) the plan simply has no hint.
-    const char* env = getenv("DAU_DYNAMIC_BUCKET");
-    p->dynamic = p->nsets > 1 && !(desc->flags & DAU_FLAG_STATIC_BUCKET) && !(env && atoi(env) == 0) &&
+    // dynamic bucket selection: tiled kernels, more than one bucket, not switched off (DAU_FLAG_STATIC_BUCKET; tuning build:
+    // DAU_DYNAMIC_BUCKET=0 in the environment at plan creation).  The pinned status mirror needs a device; without one
+    // (header-only checks on a CPU box) the plan simply has no hint.
+    p->dynamic = p->nsets > 1 && !(desc->flags & DAU_FLAG_STATIC_BUCKET) && DAU_TUNE_INT("DAU_DYNAMIC_BUCKET", 1) != 0 &&
                  (p->algo_fwd == DAU_ALGO_TILED || p->algo_bwd == DAU_ALGO_TILED);
     void* hs = nullptr;
-    if (hipHostMalloc(&hs, sizeof(Status), hipHostMallocDefault) == hipSuccess && hs) {
-        std::memset(hs, 0, sizeof(Status));
-        p->host_status = static_cast<Status*>(hs);
+    if (hipHostMalloc(&hs, sizeof(HostStatus), hipHostMallocDefault) == hipSuccess && hs) {
+        std::memset(hs, 0, sizeof(HostStatus));
+        p->host_status = static_cast<HostStatus*>(hs);
     } else {
         (void)hipGetLastError();   // no device: not an error of this call
     }
@@ -466,10 +493,14 @@ int dau_conv_plan_get_info(const dau_conv_plan* plan, dau_conv_plan_info* info) 
     info->dot_windows = plan->algo_bwd == DAU_ALGO_TILED ? plan->top().tiled_dot.windows : 0;
     info->gather_windows = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.windows : 0;
     info->bucket_sets = plan->dynamic ? plan->nsets : 1;
-    info->gather_dense_bf16 = plan->sets[0].dense_ok ? (plan->sets[0].wgrad_ok ? 2 : 1) : 0;
+    // the dense member is bucket 4: reachable as the static set itself, or through the per-call selection
+    const bool dense_reachable = plan->sets[0].dense_ok && (plan->nsets == 1 || plan->dynamic);
+    info->gather_dense_bf16 = dense_reachable ? (plan->sets[0].wgrad_ok ? 2 : 1) : 0;
     info->batch_slab_gather = plan->top().slab_gather;
     info->batch_slab_dot = plan->top().slab_dot;
     info->dot_region = plan->top().dot_ok ? plan->top().tiled_dot.region_cols * 100 + plan->top().tiled_dot.region_rows : 0;
+    info->gather_fblock = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.fblock : 0;
+    info->gather_variant = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.variant : -1;
     return DAU_OK;
 }
 
@@ -495,7 +526,7 @@ int dau_conv_forward(const dau_conv_plan* p, void* stream, const float* x, const
     launch_prepare_units(st, w, mu1, mu2, s, p->d.number_units_ignore, p->d.flags, p->bucket, false, ws.table, ws.status,
                          p->host_status);
     if (p->algo_fwd == DAU_ALGO_TILED) {
-        Candidate cand[2];
+        Candidate cand[kMaxCandidates];
         const int ncand = pick_candidates(p, ws.status, 0, cand);
         if (p->profiling) ++p->prof_passes[0];
         const size_t esize = (p->d.flags & DAU_FLAG_IO_BF16) ? 2 : 4;
@@ -539,7 +570,7 @@ int run_param_sums(const dau_conv_plan* p, hipStream_t st, const float* x, const
                          ws.status, p->host_status);
     if (p->profiling) ++p->prof_passes[2];
     if (p->algo_bwd == DAU_ALGO_TILED) {
-        Candidate cand[2];
+        Candidate cand[kMaxCandidates];
         const int ncand = pick_candidates(p, ws.status, 1, cand);
         const size_t esize = (flags & DAU_FLAG_IO_BF16) ? 2 : 4;
         for (int ci = 0; ci < ncand; ++ci) {
@@ -606,7 +637,7 @@ int dau_conv_backward(const dau_conv_plan* p, void* stream, const float* x, cons
                              p->host_status);
         if (p->profiling) ++p->prof_passes[1];
         if (p->algo_fwd == DAU_ALGO_TILED) {
-            Candidate cand[2];
+            Candidate cand[kMaxCandidates];
             const int ncand = pick_candidates(p, ws.status, 0, cand);
             const size_t esize = (flags & DAU_FLAG_IO_BF16) ? 2 : 4;
             for (int ci = 0; ci < ncand; ++ci) {
@@ -690,8 +721,12 @@ int dau_conv_last_status(const dau_conv_plan* p, float* max_abs_mu_out, int32_t*
     if (valid_out) *valid_out = 0;
     if (!p->host_status) return DAU_OK;
     const volatile unsigned* h = reinterpret_cast<const volatile unsigned*>(p->host_status);
-    if (h[2] != 1u) return DAU_OK;                       // no call has completed yet
-    const unsigned bits = h[0], nan_seen = h[1];
+    if (h[2] != 1u && h[4] == 0u && h[5] == 0u) return DAU_OK;   // no call has completed yet
+    // the sticky record first: the worst status of ANY completed call since the last report (a later good call of another
+    // layer sharing this plan must not hide it); then the most recent call
+    const unsigned bad_bits = h[4], bad_nan = h[5];
+    unsigned bits = h[0], nan_seen = h[1] | bad_nan;
+    if (bad_bits > bits) bits = bad_bits;                // non-negative float bits order like unsigned integers
     float mx;
     std::memcpy(&mx, &bits, sizeof(float));
     if (max_abs_mu_out) *max_abs_mu_out = mx;
@@ -715,10 +750,14 @@ int dau_conv_filters(const dau_conv_plan* p, void* stream, const float* sigma, f
     return DAU_OK;
 }
 
-int dau_conv_unit_table(const dau_conv_plan* p, void* stream, const float* mu1, const float* mu2, int32_t* offsets_out,
-                        float* factors_out) {
-    if (!p || !mu1 || !mu2 || !offsets_out || !factors_out) return fail(DAU_INVALID_ARGUMENT, "null argument");
-    launch_unit_table_export(static_cast<hipStream_t>(stream), mu1, mu2, p->units(), p->d.flags, offsets_out, factors_out);
+int dau_conv_unit_table(const dau_conv_plan* p, void* stream, const float* w, const float* mu1, const float* mu2, int form,
+                        void* table_out) {
+    if (!p || !mu1 || !mu2 || !table_out) return fail(DAU_INVALID_ARGUMENT, "null argument");
+    if (form != 0 && form != 1) return fail(DAU_INVALID_ARGUMENT, "form must be 0 ([S][G][F]) or 1 ([F][G][S], negated offsets)");
+    // the kernel every forward / backward call runs first, writing into the caller's buffer instead of the workspace
+    // (the input-gradient pass ignores no unit: the reference transposes the ignored units' zero weights along)
+    launch_prepare_units(static_cast<hipStream_t>(stream), w, mu1, mu2, p->sh, form == 1 ? 0 : p->d.number_units_ignore, p->d.flags,
+                         p->bucket, form == 1, static_cast<UnitRef*>(table_out), nullptr, nullptr);
     DAU_HIP(hipPeekAtLastError());
     return DAU_OK;
 }

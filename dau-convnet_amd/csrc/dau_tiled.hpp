@@ -90,7 +90,7 @@ void blur4_pack_init(int blur_k);
 bool blur4_pack_fits(int blur_k, int Hp, int Wp);
 
 // Densified parameter gradients on the bf16 matrix cores (k_dense_wgrad.hip; DAU_FLAG_DENSE_BF16, bucket 4, bfloat16
-// activations, five or more units): C_k[d][s][f] = sum_{n,q} Xk[n,s,q+d] * E'[n,f,q] for the 10 x 10 displacements d as a GEMM
+// activations, three or more units): C_k[d][s][f] = sum_{n,q} Xk[n,s,q+d] * E'[n,f,q] for the 10 x 10 displacements d as a GEMM
 // with K = (image, position), then r_k[u] = sum_taps b_t(u) * C_k[o_u + t].
 struct WgradConfig {
     Shape sh;

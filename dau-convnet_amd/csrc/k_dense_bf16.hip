@@ -389,8 +389,8 @@ void stage_tile(const DenseConfig& c, const DenseGeom& g, int* TR, int* TC, size
     // The kernel is latency bound: small tiles (about 22 x 22 positions, ~22 KiB of LDS, six workgroups per CU) beat big
     // ones although they filter more halo -- 65 x 65 planes: 16 x 65 tiles 1.32 ms, 22 x 22 tiles 0.70 ms (same box).
     int tr = (g.Hs + (g.Hs + 23) / 24 - 1) / ((g.Hs + 23) / 24), tc = (g.Ws + (g.Ws + 23) / 24 - 1) / ((g.Ws + 23) / 24);
-    if (getenv("DAU_DENSE_STAGE_TR")) tr = atoi(getenv("DAU_DENSE_STAGE_TR"));     // tuning experiments
-    if (getenv("DAU_DENSE_STAGE_TC")) tc = atoi(getenv("DAU_DENSE_STAGE_TC"));
+    tr = DAU_TUNE_INT("DAU_DENSE_STAGE_TR", tr);
+    tc = DAU_TUNE_INT("DAU_DENSE_STAGE_TC", tc);
     auto bytes = [&](int r, int cc) { return (size_t)4 * (r + c.blur_k - 1) * ((cc + c.blur_k - 1) + cc) * 4; };
     while ((bytes(tr, tc) > 52 * 1024 || tr * tc > 5 * 256) && tr > 4) tr -= 4;
     while ((bytes(tr, tc) > 52 * 1024 || tr * tc > 5 * 256) && tc > 16) tc -= 16;
@@ -407,7 +407,7 @@ bool dense_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R
     c.nsub = g.nsub;
     // accumulator tiles per wave: 1 = eight waves per workgroup, two per SIMD (default: 3.71 ms against 4.24 ms with four
     // waves at BASELINE config 2, same box); DAU_DENSE_FT=2 at plan creation selects the four-wave form
-    c.ftiles = getenv("DAU_DENSE_FT") ? atoi(getenv("DAU_DENSE_FT")) : 1;
+    c.ftiles = DAU_TUNE_INT("DAU_DENSE_FT", 1);
     if (c.ftiles != 2) c.ftiles = 1;
     int tr, tc; size_t lds;
     stage_tile(c, g, &tr, &tc, &lds);

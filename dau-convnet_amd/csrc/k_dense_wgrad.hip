@@ -1,4 +1,4 @@
-// Densified parameter gradients on the bf16 matrix cores (DAU_FLAG_DENSE_BF16; offsets within +-4, five or more units).
+// Densified parameter gradients on the bf16 matrix cores (DAU_FLAG_DENSE_BF16; offsets within +-4, three or more units).
 //
 //   r_k[s,g,f] = sum_{n,p} E'[n,f,p] * sum_{t in 2x2} b_t(s,g,f) * Xk[n,s, p + o + t]          k = w, mu1, mu2, sigma
 //             = sum_t b_t * C_k[o + t][s][f],      C_k[d][s][f] = sum_{n,p} Xk[n,s,p+d] * E'[n,f,p],   d in [-4, 5]^2
@@ -6,7 +6,7 @@
 // The 100 cross-correlations C_k[d] do not depend on the units: 400 GEMMs  M = input channels, N = output channels,
 // K = (image, position)  on v_mfma_f32_32x32x16_bf16, 2*400*N*H*W*S*F FLOP whatever the unit count -- at the rate of the
 // dense gather-sum (k_dense_bf16.hip) that is the time the exact gather-dot (k_gather_dot.hip) needs for four units, so the
-// form is used from five units on (BASELINE config 2 has six).  It replaces the same reference code as the gather-dot:
+// form is used from three units on (BASELINE config 2 has six).  It replaces the same reference code as the gather-dot:
 // DAUConv_bwd_multi_pipeline_kernel and its three preparation kernels
 // (include/dau_conv/dau_conv_impl/dau_conv_backward_core.hpp:1017-1820, 1824-2380) and the 4-filter prefilter pass
 // (src/dau_conv/util/convolve.cu:48-131).  Numerics: Xk and E' are rounded to bfloat16, products are exact, sums are fp32:

@@ -968,7 +968,7 @@ void blur4_plan(int k, int Hp, int Wp, int* wy, int* wx, size_t* lds) {
     const int WX = Wp < 64 ? Wp : 64;
     auto bytes = [&](int WY) { return ((size_t)(WY + k - 1) * (WX + k - 1) + (size_t)3 * (WY + k - 1) * WX) * 8; };
     int WY = Hp;
-    static const size_t limit = getenv("DAU_BLUR4_LDS_KB") ? (size_t)atoi(getenv("DAU_BLUR4_LDS_KB")) * 1024 : 74 * 1024;   // (env: timing experiments)
+    static const size_t limit = (size_t)DAU_TUNE_INT("DAU_BLUR4_LDS_KB", 74) * 1024;
     while (WY > 8 && bytes(WY) > limit) WY -= 8;
     *wy = WY; *wx = WX; *lds = bytes(WY);
 }
@@ -1045,10 +1045,10 @@ bool blur4_pack_fits(int blur_k, int Hp, int Wp) {
 
 bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, int ignore, TiledDotConfig* cfg) {
     // timing experiments: DAU_DOT_AS1 (one input channel per wave), DAU_DOT_NBUF=1 (one error tile), DAU_DOT_DEBUG
-    const bool as1 = getenv("DAU_DOT_AS1") != nullptr;
-    const bool one_tile = getenv("DAU_DOT_NBUF") && atoi(getenv("DAU_DOT_NBUF")) == 1;
-    const int rounds = getenv("DAU_DOT_ROUNDS") ? atoi(getenv("DAU_DOT_ROUNDS")) : 0;
-    const bool rw8 = getenv("DAU_DOT_RW") && atoi(getenv("DAU_DOT_RW")) == 8;      // 8-column regions only (A/B of the 14 x 4 form)
+    const bool as1 = DAU_TUNE_SET("DAU_DOT_AS1");
+    const bool one_tile = DAU_TUNE_INT("DAU_DOT_NBUF", 2) == 1;
+    const int rounds = DAU_TUNE_INT("DAU_DOT_ROUNDS", 0);
+    const bool rw8 = DAU_TUNE_INT("DAU_DOT_RW", 0) == 8;      // 8-column regions only (A/B of the 14 x 4 form)
     const DotGeometry g = make_dot_geometry(sh, R, as1, one_tile, rounds, rw8);
     if (g.nbuf * g.tile_bytes + 16 > 160 * 1024) return false;
     // immediates of the unrolled column walk must fit 16 bits
@@ -1061,8 +1061,8 @@ bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, int igno
     TiledDotConfig c{};
     c.sh = sh; c.R = R; c.blur_k = blur_k; c.NP = (sh.N + 1) / 2; c.variant = g.npass; c.windows = g.nsub1 * g.nsub1;
     c.bf16 = bf16; c.ignore = ignore;
-    c.ring = g.nsub1 > 1 && g.nbuf == 1 && !(getenv("DAU_DOT_RING") && atoi(getenv("DAU_DOT_RING")) == 0);
-    c.as1 = as1; c.one_tile = one_tile; c.rounds = rounds; c.rw8 = rw8; c.region_cols = g.RW; c.region_rows = g.RH; c.debug = getenv("DAU_DOT_DEBUG") ? atoi(getenv("DAU_DOT_DEBUG")) : 0;
+    c.ring = g.nsub1 > 1 && g.nbuf == 1 && DAU_TUNE_INT("DAU_DOT_RING", 1) != 0;
+    c.as1 = as1; c.one_tile = one_tile; c.rounds = rounds; c.rw8 = rw8; c.region_cols = g.RW; c.region_rows = g.RH; c.debug = DAU_TUNE_INT("DAU_DOT_DEBUG", 0);
     *cfg = c;
     return true;
 }

@@ -128,9 +128,9 @@ Geometry make_geometry(int H, int W, int R, int G, int N, int Cout, int only = -
     int want_split = 0;
     bool never_stack = false;
     if (only < 0) {
-        if (getenv("DAU_GATHER_SPLIT")) want_split = atoi(getenv("DAU_GATHER_SPLIT"));
-        never_stack = getenv("DAU_GATHER_STACK") && atoi(getenv("DAU_GATHER_STACK")) == 0;
-        if (getenv("DAU_GATHER_VARIANT")) only = atoi(getenv("DAU_GATHER_VARIANT"));
+        want_split = DAU_TUNE_INT("DAU_GATHER_SPLIT", 0);
+        never_stack = DAU_TUNE_INT("DAU_GATHER_STACK", 1) == 0;
+        only = DAU_TUNE_INT("DAU_GATHER_VARIANT", -1);
     }
     double best = 0.0;
     for (int i = 0; i < (int)(sizeof(kVariants) / sizeof(kVariants[0])); ++i) {
@@ -648,49 +648,7 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
         __syncthreads();   // plane c is in LDS for everyone; everyone is done reading plane c-1 (lagged kernels: c-2)
 #endif
 #ifdef DAU_DIAG_FUSED_BLUR
-        // Timing diagnosis (results are garbage): what filling plane c+1 INSIDE this kernel would add to a wave's
-        // instruction stream (the reference's TODO base_dau_conv_layer.hpp:160-165) -- a LOWER bound:
-        // the unit slice still arrives by DMA, the plane does not; instead every wave runs the irreducible instruction mix
-        // of its 1/8 share of a separable 7+7 tap prefilter of the 71 x 71 raw window of an image pair: raw loads ->
-        // LDS, per output position and pass 7 packed FMAs, with register blocking of four outputs per lane 2.5 LDS reads,
-        // one LDS write.  No address arithmetic, no border handling, no waits beyond one for the raw loads.
-        if (c + 1 < a.Cin) {
-            const char* us = src_units + (size_t)(c + 1) * ut_stride;
-            for (unsigned piece = wave; piece < (ut_stride >> 10); piece += T::kWaves)
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(us + (size_t)piece * 1024 + lane * 16),
-                                                 (lds_ptr_t)(smem + ut_base + nbuf * ut_stride + piece * 1024), 16, 0, 0);
-            constexpr int kRawRounds = (71 * 71 + 64 * T::kWaves - 1) / (64 * T::kWaves);       // positions per lane, raw window
-            constexpr int kOutRounds = (65 * 65 + 64 * T::kWaves - 1) / (64 * T::kWaves);       // positions per lane, staged plane
-            const unsigned wr = nbuf * buf_bytes + lane * 8, rd = buf * buf_bytes + lane * 8;
-            const char* gsrc = a.staged + (size_t)lane * 4;
-            f2 raw[kRawRounds];
-#pragma unroll
-            for (int r = 0; r < kRawRounds; ++r) {
-                asm volatile("global_load_dword %0, %2, off offset:%3\n\tglobal_load_dword %1, %2, off offset:%4"
-                             : "=&v"(raw[r].x), "=&v"(raw[r].y) : "v"(gsrc), "n"((r * 512) % 4096), "n"((r * 512 + 256) % 4096) : "memory");
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int r = 0; r < kRawRounds; ++r)
-                asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(wr), "v"(raw[r]), "n"(r * 512) : "memory");
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-                for (int r = 0; r < kOutRounds; r += 4) {            // four output positions per lane share ten reads
-                    f2 in[10];
-#pragma unroll
-                    for (int i = 0; i < 10; ++i) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(in[i]) : "v"(rd), "n"((r * 10 + i) * 512 % 32768) : "memory");
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                    for (int o = 0; o < 4; ++o) {
-                        f2 acc = in[o];
-#pragma unroll
-                        for (int t = 0; t < 7; ++t) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(in[o + t < 10 ? o + t : 9]), "v"(in[t]));
-                        asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(wr), "v"(acc), "n"(((pass * kOutRounds + r + o) * 512) % 32768) : "memory");
-                    }
-                }
-            }
-        }
+#include "diag_fused_blur.inc"   // timing diagnosis of DESIGN.md 5.3 (results are garbage); tools/ab_fused_blur.sh
 #else
         if (c + 1 < a.Cin && !((a.debug & 1) && c >= 1)) issue(c + 1, nbuf);
 #endif
@@ -859,7 +817,7 @@ size_t blur_pack_lds_bytes(const Geometry& g, int k, int band_rows = 0) {
 // 382 -> 350 us, the 68 x 104 planes of bucket 18 1784 -> 1594 us -- every band re-reads its blur halo.)
 int blur_pack_bands(const Geometry& g, int k) {
     int bands = 1;
-    static const size_t limit = getenv("DAU_BLUR_LDS_KB") ? (size_t)atoi(getenv("DAU_BLUR_LDS_KB")) * 1024 : 80 * 1024;   // (env: timing experiments)
+    static const size_t limit = (size_t)DAU_TUNE_INT("DAU_BLUR_LDS_KB", 80) * 1024;
     while (bands < 8 && blur_pack_lds_bytes(g, k, (g.rows + bands - 1) / bands) > limit) ++bands;
     return bands;
 }
@@ -881,7 +839,7 @@ bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R
     c.NP = (N + 1) / 2;
     c.rows = g.rows; c.pitch = g.pitch; c.tiles_x = g.tx; c.tiles_y = g.ty; c.fblock = g.fb; c.variant = g.variant;
     c.patches = g.npx * g.npy; c.stack = g.sk; c.windows = g.nwin1 * g.nwin1;
-    c.debug = getenv("DAU_GATHER_DEBUG") ? atoi(getenv("DAU_GATHER_DEBUG")) : 0;
+    c.debug = DAU_TUNE_INT("DAU_GATHER_DEBUG", 0);
     c.bf16 = bf16 ? 1 : 0;
     if (lds_bytes(c, g) > 160 * 1024) return false;
     // blur_pack keeps both raw planes (+ blur halo) and the horizontally filtered rows in LDS
@@ -930,7 +888,7 @@ void tiled_gather_prepare(hipStream_t st, const TiledConfig& c, const float* in,
     if (bands > 1) b.ppb = 1;
     b.planes = c.NP * c.patches * c.Cin * bands;
     b.lds_plane_floats = (unsigned)(blur_lds / 4);
-    static const int blur_threads = getenv("DAU_BLUR_THREADS") ? atoi(getenv("DAU_BLUR_THREADS")) : 512;                  // timing experiments
+    static const int blur_threads = DAU_TUNE_INT("DAU_BLUR_THREADS", 512);
     hipLaunchKernelGGL(kern, dim3((b.planes + b.ppb - 1) / b.ppb), dim3(b.ppb > 1 ? 512 : blur_threads), b.ppb * blur_lds, st, b);
     const int nfb = (c.Cout + g.fb - 1) / g.fb;
     const bool binned = g.nwin1 > 1;

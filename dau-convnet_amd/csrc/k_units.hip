@@ -26,7 +26,7 @@ __global__ void prepare_units_kernel(const float* __restrict__ w, const float* _
                                      const float* __restrict__ mu2, int S, int G, int F, int ignore,
                                      int flags, int bucket, int transposed_negated, int weight_mode,
                                      UnitRef* __restrict__ table, Status* __restrict__ status,
-                                     Status* __restrict__ host_status) {
+                                     HostStatus* __restrict__ host_status) {
     const long units = (long)S * G * F;
     unsigned int local_max = 0, local_nan = 0;
     // the loop index is the DESTINATION slot, so that the 24-byte table entries are written in order; in the transposed
@@ -77,6 +77,10 @@ __global__ void prepare_units_kernel(const float* __restrict__ w, const float* _
                     const unsigned mx = atomicMax(&status->max_abs_mu_bits, 0u), nn = atomicOr(&status->nan_seen, 0u);
                     volatile unsigned* h = reinterpret_cast<volatile unsigned*>(host_status);
                     h[0] = mx; h[1] = nn; h[2] = 1u;   // [2]: a completed call has reported
+                    // a bad status is also recorded STICKY ([4] worst max|mu| beyond the bucket, [5] NaN seen): every later
+                    // call of this plan overwrites [0..2], only the host's report clears [4..5]
+                    if (nn) h[5] = 1u;
+                    if (mx > __float_as_uint((float)bucket) && mx > h[4]) h[4] = mx;
                 }
             }
         }
@@ -85,32 +89,13 @@ __global__ void prepare_units_kernel(const float* __restrict__ w, const float* _
 
 void launch_prepare_units(hipStream_t st, const float* w, const float* mu1, const float* mu2, Shape sh,
                           int ignore, int flags, int bucket, bool transposed_negated, UnitRef* table,
-                          Status* status, Status* host_status) {
+                          Status* status, HostStatus* host_status) {
     const long units = (long)sh.S * sh.G * sh.F;
     const int block = 256;
     const int grid = (int)((units + block - 1) / block < 512 ? (units + block - 1) / block : 512);
     hipLaunchKernelGGL(prepare_units_kernel, dim3(grid), dim3(block), 0, st, w, mu1, mu2, sh.S, sh.G, sh.F,
                        ignore, flags, bucket, transposed_negated ? 1 : 0, w == nullptr ? 1 : 0, table, status,
                        status ? host_status : nullptr);
-}
-
-__global__ void unit_table_export_kernel(const float* __restrict__ mu1, const float* __restrict__ mu2,
-                                         long units, int flags, int32_t* __restrict__ offsets,
-                                         float* __restrict__ factors) {
-    for (long u = blockIdx.x * (long)blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
-        int ox, oy; float b00, b01, b10, b11;
-        unit_math(mu1[u], mu2[u], flags & DAU_FLAG_USE_INTERPOLATION, ox, oy, b00, b01, b10, b11);
-        offsets[2 * u] = ox; offsets[2 * u + 1] = oy;
-        factors[4 * u + 0] = b00; factors[4 * u + 1] = b01; factors[4 * u + 2] = b10; factors[4 * u + 3] = b11;
-    }
-}
-
-void launch_unit_table_export(hipStream_t st, const float* mu1, const float* mu2, long units, int flags,
-                              int32_t* offsets, float* factors) {
-    const int block = 256;
-    const int grid = (int)((units + block - 1) / block < 1024 ? (units + block - 1) / block : 1024);
-    hipLaunchKernelGGL(unit_table_export_kernel, dim3(grid), dim3(block), 0, st, mu1, mu2, units, flags, offsets,
-                       factors);
 }
 
 // dw = r0 ; dmu1 = w*r1*lr ; dmu2 = w*r2*lr ; dsigma = w*r3 ; ignored units -> 0 ; NaN in dmu -> 0.

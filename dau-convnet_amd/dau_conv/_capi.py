@@ -22,6 +22,8 @@ FLAG_FORBID_POSITIVE_DIM1 = 1 << 3
 FLAG_IO_BF16 = 1 << 4   # x, y, dy, dx are torch.bfloat16; parameters and their gradients stay float32
 FLAG_STATIC_BUCKET = 1 << 5   # always the kernels of the bucket max_kernel_size allows (no per-call selection)
 FLAG_DENSE_BF16 = 1 << 6      # with FLAG_IO_BF16: gather-sum passes of calls with |mu| <= 4 as a densified bf16 MFMA GEMM
+FLAG_DENSE_WGRAD_NEVER = 1 << 7    # with FLAG_DENSE_BF16: parameter gradients always through the exact fp32 gather-dot
+FLAG_DENSE_WGRAD_ALWAYS = 1 << 8   # with FLAG_DENSE_BF16: dense parameter gradients from one unit per channel on (default: three)
 
 ALGO_AUTO, ALGO_DIRECT, ALGO_TILED = 0, 1, 2
 PASS_FORWARD, PASS_BACKWARD = 1, 2
@@ -58,7 +60,7 @@ class _Desc(ctypes.Structure):
 class _Info(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ("offset_bucket", "blur_support", "algo_forward", "algo_backward", "drop_last_col", "drop_last_row",
-                 "gather_patch", "gather_stack", "dot_windows", "gather_windows", "bucket_sets", "gather_dense_bf16", "batch_slab_gather", "batch_slab_dot", "dot_region")]
+                 "gather_patch", "gather_stack", "dot_windows", "gather_windows", "bucket_sets", "gather_dense_bf16", "batch_slab_gather", "batch_slab_dot", "dot_region", "gather_fblock", "gather_variant")]
 
 
 def _load():
@@ -82,15 +84,22 @@ def _load():
     lib.dau_conv_check_status.argtypes = [vp, vp, vp, ctypes.POINTER(ctypes.c_float)]
     lib.dau_conv_last_status.argtypes = [vp, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)]
     lib.dau_conv_filters.argtypes = [vp, vp, fp, fp]
-    lib.dau_conv_unit_table.argtypes = [vp, vp, fp, fp, ip, fp]
+    lib.dau_conv_unit_table.argtypes = [vp, vp, fp, fp, fp, ctypes.c_int, vp]
+    lib.dau_conv_filter_support.argtypes = [ctypes.c_float]
+    lib.dau_conv_filter_support.restype = ctypes.c_int
     lib.dau_conv_profile_begin.argtypes = [vp]
     lib.dau_conv_profile_end.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]
-    if lib.dau_conv_abi_version() != 2:
+    if lib.dau_conv_abi_version() != 3:
         raise ImportError("dau_conv: ABI version mismatch in %s" % _LIB_PATH)
     return lib
 
 
 lib = _load()
+
+
+def filter_support(sigma):
+    """k of the k x k prefilter for this sigma (2*ceil(5*sigma)+1 in float32): all a plan keeps of sigma_hint."""
+    return int(lib.dau_conv_filter_support(ctypes.c_float(float(sigma))))
 
 
 def build_id():
@@ -285,10 +294,12 @@ class Plan(object):
             _check(lib.dau_conv_filters(self._h, _stream(sigma.device), _ptr(sigma), _ptr(out)))
         return out
 
-    def unit_table(self, mu1, mu2):
+    def unit_table(self, mu1, mu2, w=None, form=0):
+        """The table the gather kernels consume, from the kernel every call runs first: -> (offsets int32 [units, 2],
+        factors float32 [units, 4]).  form 0: [S][G][F] order (w=None: bare factors, the parameter-gradient pass);
+        form 1: [F][G][S] order with negated offsets (the input-gradient pass)."""
         units = self.S * self.G * self.F
-        off = torch.empty((units, 2), dtype=torch.int32, device=mu1.device)
-        fac = torch.empty((units, 4), dtype=torch.float32, device=mu1.device)
+        raw = torch.empty((units, 6), dtype=torch.int32, device=mu1.device)
         with torch.cuda.device(mu1.device):
-            _check(lib.dau_conv_unit_table(self._h, _stream(mu1.device), _ptr(mu1), _ptr(mu2), _ptr(off), _ptr(fac)))
-        return off, fac
+            _check(lib.dau_conv_unit_table(self._h, _stream(mu1.device), _ptr(w), _ptr(mu1), _ptr(mu2), int(form), _ptr(raw)))
+        return raw[:, :2].contiguous(), raw[:, 2:].contiguous().view(torch.float32)

@@ -18,6 +18,7 @@ Parameters keep the reference's names and shapes: `weights`, `mu1`, `mu2` [1,S,G
 `sigma` (1,), `bias` (F,)  (dau_conv.py:389-440), so checkpoints map one to one.
 There is no CPU / eager fallback: every call goes through libdau_conv_hip.so.
 """
+import collections
 import math
 import warnings
 
@@ -35,7 +36,12 @@ __all__ = ["DAUGridMean", "ZeroNLast", "DAUConv2d", "DAUConv1d", "dau_conv2d", "
 # raw ops (attr names and defaults of REGISTER_OP("DAUConv") / ("DAUConvGrad"),
 # plugins/tensorflow/src/dau_conv_op.cpp:22-48, dau_conv_grad_op.cpp:18-49)
 # ----------------------------------------------------------------------------------------------
-_PLANS = {}
+# Plans are cached per (shape, attrs, prefilter support, device) in least-recently-used order.  sigma enters a plan only
+# through the prefilter support 2*ceil(5*sigma)+1 (the taps come from the device tensor on every call), so the key holds that
+# number, not sigma: a trainable sigma changes every optimizer step and must keep hitting the same plan -- its kernel sets, its
+# offset-bucket hint and its pending status.  The cache is bounded; a dropped plan is asked for its status first.
+_PLANS = collections.OrderedDict()
+_PLAN_CACHE_MAX = 64
 
 
 def _get_plan(x, w, settings):
@@ -64,14 +70,19 @@ def _get_plan(x, w, settings):
             # as densified bf16 MFMA GEMMs
             flags |= _capi.FLAG_DENSE_BF16
     key = (N, S, F, G, H, W, settings["kernel_size"], settings["number_units_ignore"], flags, settings["algo"],
-           round(float(settings["sigma_hint"]), 6), float(settings["mu_learning_rate_factor"]), x.device.index)
+           _capi.filter_support(settings["sigma_hint"]), float(settings["mu_learning_rate_factor"]), x.device.index)
     plan = _PLANS.get(key)
-    if plan is None:
-        plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=settings["kernel_size"],
-                          number_units_ignore=settings["number_units_ignore"], flags=flags, algo=settings["algo"],
-                          sigma_hint=settings["sigma_hint"], mu_learning_rate_factor=settings["mu_learning_rate_factor"],
-                          device=x.device)
-        _PLANS[key] = plan
+    if plan is not None:
+        _PLANS.move_to_end(key)
+        return plan
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=settings["kernel_size"],
+                      number_units_ignore=settings["number_units_ignore"], flags=flags, algo=settings["algo"],
+                      sigma_hint=settings["sigma_hint"], mu_learning_rate_factor=settings["mu_learning_rate_factor"],
+                      device=x.device)
+    _PLANS[key] = plan
+    while len(_PLANS) > _PLAN_CACHE_MAX:
+        _, old = _PLANS.popitem(last=False)
+        old.last_status()        # a NaN / out-of-range offset it has seen and not yet reported is raised here, not lost
     return plan
 
 
@@ -86,7 +97,7 @@ def _check_before(plan, mode):
 def _check_after(plan, mode):
     """check_offsets=True: the reference's behaviour -- wait for the call and raise at once (the reference blocks on a
     D2H copy of the amax in every Compute, dau_conv_op.cpp:229-235)."""
-    if mode is True:
+    if mode is True:                                  # _settings normalises: "async", True or False, nothing else
         plan.check_status()
 
 
@@ -103,18 +114,22 @@ def _settings(sigma, number_units_x=2, number_units_y=2, number_units_ignore=0, 
               sigma_iteration_step=1, component_border_bound=1.0, sigma_lower_bound=0.3, merge_iteration_step=0,
               merge_threshold=1, unit_testing=False, mu_learning_rate_factor=1.0, single_dim_kernel=False,
               forbid_positive_dim1=False, use_interpolation=True, sigma_hint=None, check_offsets="async",
-              algo=_capi.ALGO_AUTO, dense_bf16=False, name=None):
+              algo=_capi.ALGO_AUTO, dense_bf16=False, process_group=None, grad_reduce="mean", name=None):
     if not unit_normalization or square_unit_normalization:
         raise _capi.InvalidArgumentError("only unit_normalization=True, square_unit_normalization=False is implemented")
     if sigma_hint is None:
         # same host read of sigma[0] the reference performs in LayerSetUp (base_dau_conv_layer.cpp:140-143)
         sigma_hint = float(sigma[(0,) * sigma.dim()].item())
+    if grad_reduce not in ("mean", "sum"):
+        raise _capi.InvalidArgumentError("grad_reduce must be \"mean\" or \"sum\"")
+    # "async" or a truth value (1, 1.0, numpy.bool_ ... count as True): nothing else reaches _check_before / _check_after
+    mode = "async" if (isinstance(check_offsets, str) and check_offsets == "async") else bool(check_offsets)
     return dict(number_units_ignore=int(number_units_ignore), num_output=int(num_output), kernel_size=int(kernel_size),
                 stride=int(stride), unit_testing=bool(unit_testing), mu_learning_rate_factor=float(mu_learning_rate_factor),
                 single_dim_kernel=bool(single_dim_kernel), forbid_positive_dim1=bool(forbid_positive_dim1),
                 use_interpolation=bool(use_interpolation), sigma_hint=float(sigma_hint),
-                check_offsets=(check_offsets if check_offsets in (True, False, "async") else bool(check_offsets)),
-                algo=int(algo), dense_bf16=bool(dense_bf16))
+                check_offsets=mode, algo=int(algo), dense_bf16=bool(dense_bf16), process_group=process_group,
+                grad_reduce=grad_reduce)
 
 
 def _c(t):
@@ -154,9 +169,43 @@ class _DAUConvFunction(torch.autograd.Function):
         if need == 0:
             return (None,) * 6
         _check_before(ctx.plan, ctx.st["check_offsets"])
-        out = ctx.plan.backward(input, _c(grad), weights, mu1, mu2, sigma, need)
+        group = ctx.st["process_group"]
+        param_need = need & ~_capi.NEED_DX
+        if group is not None and param_need and _group_size(group) > 1:
+            out = _data_parallel_backward(ctx.plan, input, _c(grad), weights, mu1, mu2, sigma, need, group,
+                                          ctx.st["grad_reduce"])
+        else:
+            out = ctx.plan.backward(input, _c(grad), weights, mu1, mu2, sigma, need)
         _check_after(ctx.plan, ctx.st["check_offsets"])
         return out + (None,)
+
+
+def _group_size(group):
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    return dist.get_world_size(None if group is True else group)
+
+
+def _data_parallel_backward(plan, input, grad, weights, mu1, mu2, sigma, need, group, grad_reduce):
+    """Backward of one batch shard in the order of SURVEY.md 8(e): raw parameter-gradient sums of the shard -> ONE asynchronous
+    all-reduce of the flat [4, S, G, F] buffer -> the dx pass runs while the floats travel -> the elementwise tail
+    (dmu *= w * lr, dsigma *= w, ignored units, NaN -> 0) on the REDUCED sums, so every rank ends bit-identical and a NaN on one
+    rank reaches all of them.  grad_reduce="mean" divides the reduced sums by the group size (what DistributedDataParallel
+    does to finalized gradients), "sum" leaves the sum over the global batch."""
+    from .distributed import OverlappedBackward
+    pg = None if group is True else group
+    world = _group_size(group)
+    ex = OverlappedBackward(weights.shape, input.device, group=pg)
+    dx_fn = (lambda: plan.backward(input, grad, weights, mu1, mu2, sigma, _capi.NEED_DX)[0]) if need & _capi.NEED_DX else None
+
+    def finalize(sums):
+        if grad_reduce == "mean":
+            sums.mul_(1.0 / world)
+        return plan.finalize_param_grads(sums, weights, need_mask=need & ~_capi.NEED_DX)
+
+    dx = ex.run(lambda out: plan.backward_param_sums(input, grad, mu1, mu2, sigma, out=out), dx_fn, finalize)
+    return (dx,) + tuple(ex.wait())
 
 
 def dau_conv(input, weights, mu1, mu2, sigma, **attrs):
@@ -267,7 +316,7 @@ class _DAUConvolution2d(object):
                  num_dau_units_ignore=0, mu_learning_rate_factor=500, dau_unit_border_bound=0.01,
                  dau_unit_sigma_bound=0.01, dau_unit_single_dim=False, dau_aggregation_forbid_positive_dim1=False,
                  dau_mu_interpolation=True, unit_testing=False, name=None, check_offsets="async", algo=_capi.ALGO_AUTO,
-                 dense_bf16=False):
+                 dense_bf16=False, process_group=None, grad_reduce="mean"):
         if len(input_shape) != 4:
             raise ValueError("Only two dimensional DAUConv supported (rank-4 NCHW input).")
         if data_format is None or data_format == "NHWC":
@@ -294,6 +343,8 @@ class _DAUConvolution2d(object):
         self.check_offsets = check_offsets
         self.algo = algo
         self.dense_bf16 = dense_bf16
+        self.process_group = process_group
+        self.grad_reduce = grad_reduce
         self.mean_max_allowed_offset = float(np.floor(self.max_kernel_size / 2.0) - self.dau_unit_border_bound)
 
     def __call__(self, inp, w, mu1, mu2, sigma, sigma_hint=None):
@@ -310,7 +361,8 @@ class _DAUConvolution2d(object):
                         forbid_positive_dim1=self.dau_aggregation_forbid_positive_dim1,
                         use_interpolation=self.dau_mu_interpolation, unit_testing=self.unit_testing,
                         sigma_hint=sigma_hint, check_offsets=self.check_offsets, algo=self.algo,
-                        dense_bf16=self.dense_bf16, name=self.name)
+                        dense_bf16=self.dense_bf16, process_group=self.process_group, grad_reduce=self.grad_reduce,
+                        name=self.name)
 
 
 class DAUConv2d(nn.Module):
@@ -325,6 +377,12 @@ class DAUConv2d(nn.Module):
     activations rounded to bf16, fp32 sums) and, from three units per channel on, their
     parameter gradients as dense cross-correlations on the same cores -- the whole step about 2x faster than the exact
     path at six units, at the bf16 tolerance.
+    `process_group` (a torch.distributed group, or True for the default one): batch-sharded data parallelism INSIDE the
+    layer's backward -- the raw parameter-gradient sums of the local shard are all-reduced (one flat [4,S,G,F] buffer, RCCL
+    over xGMI with backend "nccl") while the input gradient is computed, and the elementwise tail runs on the reduced sums;
+    weights / mu1 / mu2 / sigma gradients come out identical on every rank, averaged over the ranks (`grad_reduce="mean"`,
+    the DistributedDataParallel convention) or summed (`"sum"`).  The bias gradient is ordinary autograd and is not exchanged
+    here.  Wrapping such a layer in DistributedDataParallel as well is harmless but redundant (it averages identical values).
     """
 
     # the reference kernels process units in pairs; odd unit counts get one zero-weight ignored unit
@@ -338,7 +396,7 @@ class DAUConv2d(nn.Module):
                  bias_constraint=None, trainable=True, mu_learning_rate_factor=500, dau_unit_border_bound=0.01,
                  dau_unit_single_dim=False, dau_aggregation_forbid_positive_dim1=False, dau_sigma_trainable=False,
                  dau_mu_interpolation=True, unit_testing=False, name=None, in_channels=None, check_offsets="async",
-                 algo=_capi.ALGO_AUTO, dense_bf16=False, **kwargs):
+                 algo=_capi.ALGO_AUTO, dense_bf16=False, process_group=None, grad_reduce="mean", **kwargs):
         super(DAUConv2d, self).__init__()
         self.rank = 2
         self.filters = int(filters)
@@ -388,6 +446,8 @@ class DAUConv2d(nn.Module):
         self.check_offsets = check_offsets
         self.algo = algo
         self.dense_bf16 = dense_bf16
+        self.process_group = process_group
+        self.grad_reduce = grad_reduce
         # odd number of units: add one dummy (zero weight, ignored) unit (dau_conv.py:317-329)
         if self.num_dau_units_all % self.DAU_UNITS_GROUP != 0:
             new_num_units = int(np.ceil(self.num_dau_units_all / float(self.DAU_UNITS_GROUP)) * self.DAU_UNITS_GROUP)
@@ -472,7 +532,8 @@ class DAUConv2d(nn.Module):
             dau_unit_border_bound=self.dau_unit_border_bound, dau_unit_single_dim=self.dau_unit_single_dim,
             dau_aggregation_forbid_positive_dim1=self.dau_aggregation_forbid_positive_dim1,
             dau_mu_interpolation=self.dau_mu_interpolation, unit_testing=self.unit_testing, data_format="NCHW",
-            name=self.name, check_offsets=self.check_offsets, algo=self.algo, dense_bf16=self.dense_bf16)
+            name=self.name, check_offsets=self.check_offsets, algo=self.algo, dense_bf16=self.dense_bf16,
+            process_group=self.process_group, grad_reduce=self.grad_reduce)
         self.built = True
 
     def _var(self, key):

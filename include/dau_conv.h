@@ -29,8 +29,8 @@
  *   dau_conv_check_status /           the max|mu| / NaN precondition checks of the ops
  *   dau_conv_last_status              (dau_conv_op.cpp:223-262, dau_conv_grad_op.cpp:209-250); done on the
  *                                     device without a host sync, read back only on request (check_status waits for
- *                                     the stream; last_status reads what the most recent completed call left in
- *                                     pinned host memory, without waiting)
+ *                                     the stream; last_status reads what completed calls left in pinned host
+ *                                     memory, without waiting; a bad status stays there until it has been reported)
  *   dau_conv_filters                  BaseDAUKernelCompute::get_kernels (base_dau_conv_layer.cu:537-710)
  *   dau_conv_unit_table               perpare_weights_and_offsets (dau_conv_forward_core.hpp:1858-2215)
  *   dau_conv_last_error               DAUException::what (include/dau_conv/util/common.hpp:40-66)
@@ -43,9 +43,10 @@
  * Ownership: the caller owns every buffer, including one workspace per in-flight call.
  * A plan's configuration is immutable after creation, so concurrent calls on different
  * streams with different workspaces are safe.  Only dau_conv_plan_create / _destroy allocate
- * (the plan and 16 bytes of pinned host memory for its status mirror) and only
+ * (the plan and 32 bytes of pinned host memory for its status mirror) and only
  * dau_conv_check_status synchronises (it waits for the stream); no other call allocates,
- * frees or synchronises.  Create a plan with the device current on which it will run.
+ * frees or synchronises.  A plan may be used on any device (the kernels' launch attributes are
+ * set once per device, on the first call there, behind a lock).
  * dau_conv_backward OVERWRITES the gradient outputs (the reference op zero-fills them and
  * then accumulates, dau_conv_grad_op.cpp:202-205 -- same net result).
  *
@@ -54,7 +55,9 @@
  * (dau_conv_op.cpp:223-253).  Here a plan holds the kernel sets of every R up to the one
  * max_kernel_size allows; a call enqueues the set that covered the previous call's max|mu|
  * (read from the pinned mirror, no sync) plus the largest set, each guarded on the device by
- * THIS call's max|mu|, so exactly one does the work and results never depend on the hint.
+ * THIS call's max|mu|, so exactly one does the work and results never depend on the hint (with
+ * DAU_FLAG_DENSE_BF16 the bucket-4 member, the only one with bf16 arithmetic, is enqueued as a guarded
+ * candidate on EVERY call, so that too is decided by the call's own offsets alone).
  *
  * Workspace.  Every pass stages its input before it gathers.  Where the staged copy of the
  * whole batch would exceed 12 GB (DAU_WORKSPACE_BUDGET_GB in the environment at plan
@@ -76,7 +79,7 @@
 extern "C" {
 #endif
 
-#define DAU_CONV_ABI_VERSION 2
+#define DAU_CONV_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define DAU_API __attribute__((visibility("default")))
@@ -112,6 +115,10 @@ enum {
                                                and -- from three units per channel on -- their parameter gradients as dense cross-correlations on the
                                                same matrix cores (filtered input and error rounded to bf16, fp32
                                                sums).  Otherwise the exact fp32 path.                        */
+    DAU_FLAG_DENSE_WGRAD_NEVER = 1 << 7,    /* with DAU_FLAG_DENSE_BF16: keep the exact fp32 gather-dot for the
+                                               parameter gradients whatever the unit count                   */
+    DAU_FLAG_DENSE_WGRAD_ALWAYS = 1 << 8,   /* with DAU_FLAG_DENSE_BF16: dense parameter gradients from ONE unit
+                                               per channel on (default: from three, where they start to pay) */
     DAU_FLAG_DEFAULT = DAU_FLAG_USE_INTERPOLATION
 };
 
@@ -174,6 +181,9 @@ typedef struct dau_conv_plan_info {
                                   unless the staged copy would exceed the workspace budget)      */
     int32_t dot_region;        /* tiled gather-dot of the static bucket: 100 * columns + rows of the
                                   positions one sweep covers (808, 807, 1404, 804; 0: direct)     */
+    int32_t gather_fblock;     /* tiled gather-sum y pass of the static bucket: output channels per
+                                  workgroup (4, 8, 12, 16; 0: direct)                             */
+    int32_t gather_variant;    /* ... and the row of its kernel table (k_gather_mfma.hip kVariants) */
 } dau_conv_plan_info;
 
 DAU_API int dau_conv_abi_version(void);
@@ -181,6 +191,10 @@ DAU_API int dau_conv_abi_version(void);
  * header), set by the Makefile: measurement files (profiles/) name the build they were taken from by it. */
 DAU_API const char *dau_conv_build_id(void);
 DAU_API const char *dau_conv_last_error(void); /* thread-local message of the last failing call */
+
+/* Support k of the k x k prefilter a sigma needs: 2*ceil(5*sigma)+1 in float32 (base_dau_conv_layer.cpp:146).  A plan depends on
+ * sigma_hint only through this number, so callers that cache plans key them on it (a trainable sigma changes every step). */
+DAU_API int dau_conv_filter_support(float sigma);
 
 DAU_API int dau_conv_plan_create(const dau_conv_desc *desc, dau_conv_plan **plan_out);
 DAU_API int dau_conv_plan_destroy(dau_conv_plan *plan);
@@ -215,17 +229,24 @@ DAU_API int dau_conv_finalize_param_grads(const dau_conv_plan *plan, void *strea
 DAU_API int dau_conv_check_status(const dau_conv_plan *plan, void *stream, const void *workspace,
                           float *max_abs_mu_out);
 
-/* The same report without waiting: what the most recent COMPLETED forward/backward call of this plan found (read
- * from pinned host memory).  valid_out = 0 when no call has completed yet (then DAU_OK).  A caller that checks this
- * before each call learns of a NaN / out-of-range offset one call late, without ever stalling the stream. */
+/* The same report without waiting, from pinned host memory.  A NaN or an out-of-range offset seen by ANY completed call of
+ * this plan since the last report is STICKY: it stays until this function (or dau_conv_check_status) has returned it once,
+ * however many good calls completed in between -- plans are shared by all layers of one shape, and a later layer's clean
+ * status must not hide an earlier layer's error.  Without such an error: DAU_OK and max|mu| of the most recent completed
+ * call (valid_out = 0 when none has completed yet).  A caller that checks this before each call learns of a bad offset
+ * at most a few calls late, without ever stalling the stream. */
 DAU_API int dau_conv_last_status(const dau_conv_plan *plan, float *max_abs_mu_out, int32_t *valid_out);
 
 /* Building blocks exposed for parity tests (device pointers in and out).
  * filters_out: 6 planes of k*k floats in the order Gn, Dw, Dmu1, Dmu2, Dsigma, Gerr.
- * unit table: offsets_out[2*u] = floor(mu1), [2*u+1] = floor(mu2); factors_out[4*u + 2*dy + dx]. */
+ * unit table: THE table the gather kernels consume, written by the very kernel every forward / backward call runs first
+ * (prepare_units_kernel): S*G*F entries of 6 dwords {int32 floor(mu1'), int32 floor(mu2'), float w'*b00, w'*b01, w'*b10,
+ * w'*b11} (factor index 2*dy + dx).  form 0: entry order [S][G][F], mu' = mu (forward, and with w = NULL -> w' = 1 the
+ * parameter-gradient pass); form 1: entry order [F][G][S], mu' = -mu (the input-gradient pass,
+ * base_dau_conv_layer.cu:299-325).  Ignored units have w' = 0. */
 DAU_API int dau_conv_filters(const dau_conv_plan *plan, void *stream, const float *sigma, float *filters_out);
-DAU_API int dau_conv_unit_table(const dau_conv_plan *plan, void *stream, const float *mu1, const float *mu2,
-                        int32_t *offsets_out, float *factors_out);
+DAU_API int dau_conv_unit_table(const dau_conv_plan *plan, void *stream, const float *w, const float *mu1, const float *mu2,
+                        int form, void *table_out);
 
 /* Optional per-kernel timing for benchmarks (no reference counterpart; the reference only has the
  * compile-time PROFILE_CUDA block, dau_conv_forward_core.hpp:2506-2563).  Between _begin and _end every

@@ -11,6 +11,7 @@
 //         -L../../dau-convnet_amd/dau_conv -ldau_conv_hip -o dau_conv_op.so
 #include <hip/hip_runtime.h>
 
+#include <list>
 #include <map>
 #include <mutex>
 #include <string>
@@ -134,25 +135,41 @@ hipStream_t StreamOf(tf::OpKernelContext* ctx) {
     return *reinterpret_cast<hipStream_t*>(ctx->op_device_context()->stream()->platform_specific_handle().stream);
 }
 
-// Plans are kept per op instance, keyed by the descriptor (shapes + attrs + sigma): creating one is cheap, but a kept plan
-// carries the offset-bucket hint from call to call (include/dau_conv.h, "Offset buckets"), which is what lets a layer with a
-// large max_kernel_size and small offsets run the small-offset kernels, as the reference's per-call amax does
-// (dau_conv_op.cpp:223-253).
+// Plans are kept per op instance, keyed by the descriptor: creating one is cheap, but a kept plan carries the offset-bucket
+// hint from call to call (include/dau_conv.h, "Offset buckets"), which is what lets a layer with a large max_kernel_size and
+// small offsets run the small-offset kernels, as the reference's per-call amax does (dau_conv_op.cpp:223-253).
+// sigma enters a plan only through the prefilter support 2*ceil(5*sigma)+1, so the key holds the descriptor with sigma_hint
+// replaced by the smallest sigma of that support: a trainable sigma (new value every step) keeps hitting the same plan.  The
+// cache is bounded (least recently used plan dropped; an op sees a handful of shapes in its life).
 class PlanCache {
   public:
-    ~PlanCache() { for (auto& kv : plans_) dau_conv_plan_destroy(kv.second); }
+    static constexpr size_t kMaxPlans = 16;
+    ~PlanCache() { for (auto& e : plans_) dau_conv_plan_destroy(e.second); }
     int Get(const dau_conv_desc& d, dau_conv_plan** plan) {
-        const std::string key(reinterpret_cast<const char*>(&d), sizeof(d));
+        dau_conv_desc canon = d;
+        canon.sigma_hint = static_cast<float>(dau_conv_filter_support(d.sigma_hint));   // the support stands in for sigma
+        const std::string key(reinterpret_cast<const char*>(&canon), sizeof(canon));
         std::lock_guard<std::mutex> lock(mu_);
-        auto it = plans_.find(key);
-        if (it != plans_.end()) { *plan = it->second; return DAU_OK; }
+        for (auto it = plans_.begin(); it != plans_.end(); ++it)
+            if (it->first == key) {
+                plans_.splice(plans_.begin(), plans_, it);                               // most recently used first
+                *plan = plans_.front().second;
+                return DAU_OK;
+            }
         const int rc = dau_conv_plan_create(&d, plan);
-        if (rc == DAU_OK) plans_.emplace(key, *plan);
-        return rc;
+        if (rc != DAU_OK) return rc;
+        plans_.emplace_front(key, *plan);
+        while (plans_.size() > kMaxPlans) {
+            // Compute checks every call's status synchronously (dau_conv_check_status), so a dropped plan has nothing pending;
+            // no other thread can still hold it: TF serialises the Compute calls of one op instance on its stream
+            dau_conv_plan_destroy(plans_.back().second);
+            plans_.pop_back();
+        }
+        return DAU_OK;
     }
   private:
     std::mutex mu_;
-    std::map<std::string, dau_conv_plan*> plans_;
+    std::list<std::pair<std::string, dau_conv_plan*>> plans_;
 };
 
 class DAUConvOp : public tf::OpKernel {

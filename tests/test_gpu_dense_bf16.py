@@ -84,15 +84,14 @@ def test_dense_bf16_gather_against_oracle(shape):
     dict(N=3, S=5, F=8, G=2, H=4, W=130),         # 5 x 28 (140)
 ])
 @pytest.mark.parametrize("unit_testing", [False, True])
-def test_dense_parameter_gradients_against_oracle(shape, unit_testing, monkeypatch):
-    """k_dense_wgrad.hip on its own: DAU_DENSE_WGRAD=1 takes the dense correlations from one unit on."""
+def test_dense_parameter_gradients_against_oracle(shape, unit_testing):
+    """k_dense_wgrad.hip on its own: DAU_FLAG_DENSE_WGRAD_ALWAYS takes the dense correlations from one unit on."""
     from dau_conv import _capi
-    monkeypatch.setenv("DAU_DENSE_WGRAD", "1")
     N, S, F, G, H, W = (shape[q] for q in ("N", "S", "F", "G", "H", "W"))
     xb, dyb, w, mu1, mu2 = _case(47, N, S, F, G, H, W, 3.99)
     mu1.flat[0] = 3.99; mu2.flat[0] = -3.99; mu1.flat[1] = -4.0; mu2.flat[1] = 4.0       # the corners of the displacement range
     flags = _capi.FLAG_USE_INTERPOLATION | _capi.FLAG_IO_BF16 | _capi.FLAG_DENSE_BF16 | (_capi.FLAG_UNIT_TESTING if unit_testing else 0)
-    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=flags)
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=flags | _capi.FLAG_DENSE_WGRAD_ALWAYS)
     assert plan.info["gather_dense_bf16"] == 2
     dev = lambda a: torch.from_numpy(a).cuda()
     sigma = torch.full((1, S, G, F), 0.5, device="cuda")
@@ -102,8 +101,7 @@ def test_dense_parameter_gradients_against_oracle(shape, unit_testing, monkeypat
     for t, key in zip(got[1:], ("dw", "dmu1", "dmu2", "dsigma")):
         assert_parity(t.cpu().numpy(), want[key], key, rel=2e-2, floor=4e-3)
     # and against the exact gather-dot of the same plan shape (fp32 arithmetic on the same bf16 inputs)
-    monkeypatch.setenv("DAU_DENSE_WGRAD", "0")
-    exact = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=flags)
+    exact = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=flags | _capi.FLAG_DENSE_WGRAD_NEVER)
     assert exact.info["gather_dense_bf16"] == 1
     ref = exact.backward(xb.cuda(), dyb.cuda(), dev(w), dev(mu1), dev(mu2), sigma)
     for a, b, key in zip(got[1:], ref[1:], ("dw", "dmu1", "dmu2", "dsigma")):
@@ -126,6 +124,29 @@ def test_dense_bf16_under_a_larger_kernel_follows_the_offsets():
     _check(y, g, *big, "large offsets (gather)")
     y, g = _run(plan, *big)
     _check(y, g, *big, "large offsets again")
+
+
+def test_dense_arithmetic_depends_on_the_offsets_only_not_on_the_hint():
+    """With DAU_FLAG_DENSE_BF16 the bucket-4 member is the one kernel set whose arithmetic differs (bf16 products).  It is
+    enqueued as a guarded candidate on EVERY call, so the first call of a plan (no hint), a hinted call and a call after a
+    stale hint (larger offsets in between) give the same bits for the same inputs."""
+    from dau_conv import _capi
+    N, S, F, G, H, W = 3, 10, 24, 4, 20, 26
+    flags = _capi.FLAG_USE_INTERPOLATION | _capi.FLAG_IO_BF16 | _capi.FLAG_DENSE_BF16
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=33, sigma_hint=0.5, flags=flags)
+    assert plan.info["gather_dense_bf16"] == 2 and plan.info["bucket_sets"] == 3
+    small = _case(52, N, S, F, G, H, W, 3.5)
+    y1, g1 = _run(plan, *small)                            # no hint yet
+    y2, g2 = _run(plan, *small)                            # hinted: bucket 4
+    mid = _case(53, N, S, F, G, H, W, 7.0)
+    ym, gm = _run(plan, *mid)                              # bucket 8 (exact fp32 gather), leaves a hint of 7
+    _check(ym, gm, *mid, "bucket 8 between two dense calls")
+    y3, g3 = _run(plan, *small)                            # stale hint of 7: dense, bucket-8 and static candidates, dense runs
+    _check(y1, g1, *small, "first call (dense)", dense_params=True)
+    for a, b, c, name in zip((y1,) + tuple(g1), (y2,) + tuple(g2), (y3,) + tuple(g3), ("y", "dx", "dw", "dmu1", "dmu2", "dsigma")):
+        assert torch.equal(a, b) and torch.equal(a, c), name
+    static = _capi.Plan(N, S, F, G, H, W, max_kernel_size=33, sigma_hint=0.5, flags=flags | _capi.FLAG_STATIC_BUCKET)
+    assert static.info["gather_dense_bf16"] == 0           # the dense member is unreachable: not reported
 
 
 def test_dense_flag_needs_bf16_io():

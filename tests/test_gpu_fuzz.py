@@ -105,7 +105,7 @@ def test_random_configuration_dense_bf16(seed):
     sigma = c["sigma"] if c["sigma"] <= 0.8 else 0.5
     plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, number_units_ignore=c["ignore"], flags=fl, sigma_hint=sigma)
     assert plan.info["gather_dense_bf16"] in (1, 2)
-    dense_params = plan.info["gather_dense_bf16"] == 2           # five or more units: dense parameter gradients, bf16 bar
+    dense_params = plan.info["gather_dense_bf16"] == 2           # three or more units: dense parameter gradients, bf16 bar
     dev = lambda a: torch.from_numpy(a).cuda()
     sig = torch.full((1, S, G, F), sigma, device="cuda")
     for _ in range(2):                                  # kernel 17: the second round is the hinted (dense) one

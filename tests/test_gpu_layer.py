@@ -58,28 +58,65 @@ def _run_DAUConv_forward_and_backward(N, W, H, S, F, dau_uints, max_kernel_size,
     return op
 
 
-@pytest.mark.parametrize("cfg", [
-    # dau_conv_test.py:418-437 test_DAUConvQuick (channel counts reduced where the oracle would take minutes)
+# The reference's own shape matrix, verbatim (batch, channel counts, image sizes, units, kernels, offset ranges): the C oracle
+# takes well under a second for the largest of them on the GPU box's host cores, so nothing is reduced.
+_QUICK = [  # dau_conv_test.py:418-437 test_DAUConvQuick
     dict(N=2, W=65, H=8, S=33, F=32, dau_uints=(1, 2), max_kernel_size=9, max_offset_init=3),
+    dict(N=1, W=65, H=8, S=32, F=32, dau_uints=(1, 2), max_kernel_size=9, max_offset_init=3),
     dict(N=1, W=8, H=8, S=32, F=32, dau_uints=(1, 2), max_kernel_size=9, max_offset_init=3),
     dict(N=4, W=8, H=8, S=32, F=32, dau_uints=(1, 2), max_kernel_size=9, max_offset_init=3),
-    dict(N=4, W=32, H=32, S=16, F=32, dau_uints=(2, 2), max_kernel_size=9, max_offset_init=3),
-    dict(N=4, W=32, H=32, S=16, F=32, dau_uints=(2, 2), max_kernel_size=17, max_offset_init=6),
-    dict(N=4, W=32, H=32, S=16, F=32, dau_uints=(2, 2), max_kernel_size=17, max_offset_init=3),
-    dict(N=4, W=32, H=32, S=3, F=32, dau_uints=(2, 2), max_kernel_size=17, max_offset_init=3),
-    dict(N=2, W=64, H=64, S=3, F=32, dau_uints=(2, 2), max_kernel_size=33, max_offset_init=10),
+    dict(N=16, W=32, H=32, S=32, F=32, dau_uints=(2, 2), max_kernel_size=9, max_offset_init=3),
+    dict(N=16, W=32, H=32, S=32, F=32, dau_uints=(2, 2), max_kernel_size=17, max_offset_init=6),
+    dict(N=16, W=32, H=32, S=32, F=32, dau_uints=(2, 2), max_kernel_size=17, max_offset_init=3),
+    dict(N=16, W=32, H=32, S=3, F=32, dau_uints=(2, 2), max_kernel_size=17, max_offset_init=3),
+    dict(N=16, W=64, H=64, S=3, F=32, dau_uints=(2, 2), max_kernel_size=33, max_offset_init=10),
+]
+_FULL = [  # dau_conv_test.py:439-465 test_DAUConv: the cases Quick does not already hold
+    dict(N=2, W=65, H=8, S=32, F=32, dau_uints=(1, 2), max_kernel_size=9, max_offset_init=3),
+    dict(N=2, W=8, H=8, S=32, F=32, dau_uints=(1, 2), max_kernel_size=9, max_offset_init=3),
+    dict(N=16, W=6, H=6, S=64, F=256, dau_uints=(2, 1), max_kernel_size=17, max_offset_init=8),
+    dict(N=16, W=64, H=64, S=32, F=32, dau_uints=(2, 2), max_kernel_size=33, max_offset_init=10),
+    dict(N=16, W=64, H=64, S=32, F=32, dau_uints=(2, 2), max_kernel_size=65, max_offset_init=20),
+]
+_INTERPOLATION = [  # dau_conv_test.py:467-501 test_DAUConvInterpolation (use_interpolation=False)
+    dict(N=2, W=65, H=8, S=32, F=32, dau_uints=(1, 2), max_kernel_size=9, max_offset_init=3),
+    dict(N=1, W=65, H=8, S=32, F=32, dau_uints=(1, 2), max_kernel_size=9, max_offset_init=3),
+    dict(N=1, W=8, H=8, S=32, F=32, dau_uints=(1, 2), max_kernel_size=9, max_offset_init=3),
+    dict(N=2, W=8, H=8, S=32, F=32, dau_uints=(1, 2), max_kernel_size=9, max_offset_init=3),
+    dict(N=4, W=8, H=8, S=32, F=32, dau_uints=(1, 2), max_kernel_size=9, max_offset_init=3),
+    dict(N=16, W=32, H=32, S=32, F=32, dau_uints=(2, 2), max_kernel_size=9, max_offset_init=3),
+    dict(N=16, W=32, H=32, S=32, F=32, dau_uints=(2, 2), max_kernel_size=17, max_offset_init=6),
+    dict(N=16, W=6, H=6, S=64, F=256, dau_uints=(2, 1), max_kernel_size=17, max_offset_init=8),
+    dict(N=16, W=32, H=32, S=32, F=32, dau_uints=(2, 2), max_kernel_size=17, max_offset_init=3),
+    dict(N=16, W=64, H=64, S=16, F=32, dau_uints=(2, 2), max_kernel_size=33, max_offset_init=10),
+    dict(N=16, W=64, H=64, S=32, F=32, dau_uints=(2, 2), max_kernel_size=33, max_offset_init=10),
+    dict(N=16, W=64, H=64, S=32, F=32, dau_uints=(2, 2), max_kernel_size=65, max_offset_init=20),
+]
+
+
+def _id(c):
+    return "N%d_%dx%d_S%d_F%d_u%dx%d_k%d_m%d" % (c["N"], c["H"], c["W"], c["S"], c["F"], c["dau_uints"][0], c["dau_uints"][1],
+                                                 c["max_kernel_size"], c["max_offset_init"])
+
+
+@pytest.mark.parametrize("cfg", _QUICK + [
     # :631-633 test_DAUConvSingleUnit -- one unit becomes two with one ignored
     dict(N=4, W=32, H=32, S=8, F=16, dau_uints=(1, 1), max_kernel_size=9, max_offset_init=3),
     # mu beyond the clip range: clipped units must get zero mu gradient
     dict(N=2, W=16, H=16, S=4, F=8, dau_uints=(2, 2), max_kernel_size=9, max_offset_init=6),
-])
+], ids=_id)
 def test_DAUConvQuick(cfg):
     _run_DAUConv_forward_and_backward(**cfg)
 
 
-def test_DAUConvInterpolationOff():
-    _run_DAUConv_forward_and_backward(N=2, W=32, H=32, S=8, F=32, dau_uints=(2, 2), max_kernel_size=9, max_offset_init=3,
-                                      use_interpolation=False)
+@pytest.mark.parametrize("cfg", _FULL, ids=_id)
+def test_DAUConv(cfg):
+    _run_DAUConv_forward_and_backward(**cfg)
+
+
+@pytest.mark.parametrize("cfg", _INTERPOLATION, ids=_id)
+def test_DAUConvInterpolation(cfg):
+    _run_DAUConv_forward_and_backward(use_interpolation=False, **cfg)
 
 
 def test_DAUConv1d():
@@ -152,6 +189,39 @@ def test_async_offset_check_raises_one_call_late_without_a_sync():
     with pytest.raises(dau_conv.InvalidArgumentError):
         dau_conv.check_pending_offsets()
     dau_conv.dau_conv(x, w, mu, mu, sigma, num_output=4, kernel_size=9, check_offsets=False)
+    dau_conv.check_pending_offsets()
+
+
+def test_bad_offsets_of_a_middle_layer_are_not_overwritten_by_later_calls():
+    """Plans are shared by every layer of one shape.  Three calls A1, A2, A3 of one plan where only A2 has bad offsets: A3
+    overwrites the plan's 'most recent call' status, so the bad one has to be recorded STICKY in the pinned mirror until the
+    host has reported it (the kernels keep going with a NaN offset read as 0 and a far one clamped: training would
+    continue silently wrong)."""
+    import dau_conv
+    import importlib
+    dc = importlib.import_module("dau_conv.dau_conv")        # (the package attribute of that name is the op function)
+    x = torch.rand(2, 3, 10, 12, device="cuda")
+    w = torch.randn(1, 3, 2, 4, device="cuda")
+    mu = torch.zeros(1, 3, 2, 4, device="cuda")
+    sigma = torch.full((1, 3, 2, 4), 0.5, device="cuda")
+    call = lambda m1: dau_conv.dau_conv(x, w, m1, mu, sigma, num_output=4, kernel_size=9, check_offsets=False)
+    for bad_value, error in ((float("nan"), dau_conv.FailedPreconditionError), (7.5, dau_conv.InvalidArgumentError)):
+        bad = mu.clone(); bad[0, 2, 1, 3] = bad_value
+        call(mu); call(bad); call(mu); call(mu)
+        torch.cuda.synchronize()
+        plan = dc._get_plan(x, w, dc._settings(sigma, num_output=4, kernel_size=9))
+        with pytest.raises(error):
+            plan.last_status()
+        assert plan.last_status() == 0.0                   # reported once; the mirror is clean again
+        call(mu)
+        dau_conv.check_pending_offsets()
+    # the same through the default mode: the error surfaces on a later call although good calls ran in between
+    bad = mu.clone(); bad[0, 0, 0, 0] = float("nan")
+    dau_conv.dau_conv(x, w, bad, mu, sigma, num_output=4, kernel_size=9)
+    call(mu); call(mu)
+    torch.cuda.synchronize()
+    with pytest.raises(dau_conv.FailedPreconditionError):
+        dau_conv.dau_conv(x, w, mu, mu, sigma, num_output=4, kernel_size=9)
     dau_conv.check_pending_offsets()
 
 

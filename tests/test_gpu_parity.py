@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import dau_oracle as orc
-from util import assert_parity, case_kernel_size, golden_cases, load_case
+from util import assert_parity, case_kernel_size, golden_cases, load_case, tuning_capi
 
 pytestmark = pytest.mark.gpu
 
@@ -99,20 +99,44 @@ def test_mu_learning_rate_factor_and_need_mask():
 
 
 def test_unit_bookkeeping_bit_exact():
-    """floor(mu), fractions and the four bilinear factors are bit-identical to the oracle."""
+    """floor(mu), fractions and the four bilinear factors are bit-identical to the oracle -- in THE table the gather kernels
+    consume (dau_conv_unit_table runs prepare_units_kernel, the first kernel of every call, into the caller's buffer), in
+    all three forms a step uses: [S][G][F] with bare factors (parameter gradients, dau_conv_backward_core.hpp:2078-2081),
+    [S][G][F] premultiplied by w (forward, dau_conv_forward_core.hpp:2025-2028,2135-2213) and [F][G][S] with negated offsets
+    premultiplied by w (input gradient, base_dau_conv_layer.cu:299-325); an ignored unit has zero factors."""
     from dau_conv import _capi
     rs = np.random.RandomState(3)
-    S, G, F = 5, 4, 24
+    S, G, F, ignore = 5, 4, 24, 1
     mu1 = rs.uniform(-8, 8, (1, S, G, F)).astype(np.float32)
     mu2 = rs.uniform(-8, 8, (1, S, G, F)).astype(np.float32)
     mu1.flat[:6] = [-8.0, 8.0, 7.99, -7.99, -0.0, 3.0]
     mu2.flat[:6] = [8.0, -8.0, -7.99, 7.99, 1e-8, -3.0]
+    w = (rs.randn(1, S, G, F) * 0.1).astype(np.float32)
+    live = (np.arange(G) < G - ignore).astype(np.float32).reshape(1, 1, G, 1)
+    bits = lambda a: np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
     for interp in (True, False):
-        plan = _capi.Plan(1, S, F, G, 8, 8, max_kernel_size=17, flags=_capi.FLAG_USE_INTERPOLATION if interp else 0)
+        plan = _capi.Plan(1, S, F, G, 8, 8, max_kernel_size=17, number_units_ignore=ignore,
+                          flags=_capi.FLAG_USE_INTERPOLATION if interp else 0)
+        eoff, efac = orc.unit_table(mu1, mu2, use_interpolation=interp)          # [S*G*F] in SGF order
+        # parameter-gradient pass: bare factors (ignored units: zero)
         off, fac = plan.unit_table(_dev(mu1), _dev(mu2))
-        eoff, efac = orc.unit_table(mu1, mu2, use_interpolation=interp)
         assert np.array_equal(off.cpu().numpy(), eoff)
-        assert np.array_equal(fac.cpu().numpy().view(np.uint32), efac.view(np.uint32))
+        want = efac.reshape(S, G, F, 4) * live.reshape(1, G, 1, 1)
+        assert np.array_equal(bits(fac.cpu().numpy()), bits(want.reshape(-1, 4)))
+        # forward pass: premultiplied by w
+        off, fac = plan.unit_table(_dev(mu1), _dev(mu2), w=_dev(w))
+        assert np.array_equal(off.cpu().numpy(), eoff)
+        wl = (w * live).reshape(S, G, F, 1).astype(np.float32)
+        want = wl * efac.reshape(S, G, F, 4)                                      # one fp32 multiply, as the kernel does
+        assert np.array_equal(bits(fac.cpu().numpy()), bits(want.reshape(-1, 4)))
+        # input-gradient pass: [F][G][S] order, offsets negated (floor(-mu), its own fractions), premultiplied by w; every
+        # unit is live here (the reference transposes the zero weights of ignored units along, :299-325)
+        noff, nfac = orc.unit_table(-mu1, -mu2, use_interpolation=interp)
+        off, fac = plan.unit_table(_dev(mu1), _dev(mu2), w=_dev(w), form=1)
+        t = lambda a, c: np.ascontiguousarray(a.reshape(S, G, F, c).transpose(2, 1, 0, 3)).reshape(-1, c)
+        assert np.array_equal(off.cpu().numpy(), t(noff, 2))
+        want = w.reshape(S, G, F, 1).astype(np.float32) * nfac.reshape(S, G, F, 4)
+        assert np.array_equal(bits(fac.cpu().numpy()), bits(t(want, 4)))
 
 
 @pytest.mark.parametrize("sigma,sd,fp", [(0.5, 0, 0), (0.8, 0, 0), (1.2, 0, 0), (0.5, 1, 0), (0.5, 1, 1)])
@@ -273,8 +297,10 @@ def test_seeded_shapes_against_c_oracle(shape, algo):
     dict(N=2, W=64, H=40, S=4, F=26, G=5, k=49, m=23.5, variant=22, stack=1, patch=32),  # twelve channels, 31 pixel patches
 ])
 def test_stacked_gather_variants(shape, monkeypatch):
-    from dau_conv import _capi
-    monkeypatch.setenv("DAU_GATHER_VARIANT", str(shape["variant"]))   # read at plan creation only
+    # the tuning build of the same sources: only it reads DAU_GATHER_VARIANT (at plan creation); the release library picks these
+    # rows by itself for the large batches they were made for
+    _capi = tuning_capi()
+    monkeypatch.setenv("DAU_GATHER_VARIANT", str(shape["variant"]))
     rs = np.random.RandomState(11)
     N, S, F, G, H, W, k, m = (shape[q] for q in ("N", "S", "F", "G", "H", "W", "k", "m"))
     x = rs.rand(N, S, H, W).astype(np.float32)
@@ -284,7 +310,7 @@ def test_stacked_gather_variants(shape, monkeypatch):
     mu2 = np.clip(rs.uniform(-m, m, (1, S, G, F)), -lim, lim).astype(np.float32)
     dy = rs.randn(N, F, H, W).astype(np.float32)
     plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, sigma_hint=0.5)
-    assert plan.info["algo_forward"] == _capi.ALGO_TILED
+    assert plan.info["algo_forward"] == _capi.ALGO_TILED and plan.info["gather_variant"] == shape["variant"]
     assert (plan.info["gather_stack"], plan.info["gather_patch"]) == (shape["stack"], shape["patch"]), plan.info
     sigma = torch.full((1, S, G, F), 0.5, device="cuda")
     y = plan.forward(_dev(x), _dev(w), _dev(mu1), _dev(mu2), sigma)
@@ -326,9 +352,9 @@ def test_gather_dot_region_forms(shape, monkeypatch):
     for t, key in zip(got, ("dx", "dw", "dmu1", "dmu2", "dsigma")):
         assert_parity(t.cpu().numpy(), want[key], key)
     if shape["region"] == 1404:
-        # the 8-column form of the same plan (DAU_DOT_RW=8 at plan creation) agrees to rounding
+        # the 8-column form of the same plan (tuning build, DAU_DOT_RW=8 at plan creation) agrees to rounding
         monkeypatch.setenv("DAU_DOT_RW", "8")
-        plan8 = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=_capi.FLAG_USE_INTERPOLATION | _capi.FLAG_UNIT_TESTING)
+        plan8 = tuning_capi().Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=_capi.FLAG_USE_INTERPOLATION | _capi.FLAG_UNIT_TESTING)
         assert plan8.info["dot_region"] in (807, 808), plan8.info
         got8 = plan8.backward(_dev(x), _dev(dy), _dev(w), _dev(mu1), _dev(mu2), sigma)
         for a8, a14, key in zip(got8[1:], got[1:], ("dw", "dmu1", "dmu2", "dsigma")):

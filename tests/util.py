@@ -48,3 +48,72 @@ def case_kernel_size(c):
         if m <= k // 2:
             return k
     raise ValueError(m)
+
+
+def make_inputs(seed, N, S, F, G, H, W, k, m, ignore=0):
+    """Synthetic tensors of SURVEY.md 8(d): x ~ U[0,1), dy ~ N(0,1), w ~ N(0, 0.1^2), mu ~ U(-m, m) clipped to the kernel."""
+    rs = np.random.RandomState(seed)
+    x = rs.rand(N, S, H, W).astype(np.float32)
+    dy = rs.randn(N, F, H, W).astype(np.float32)
+    w = (rs.randn(1, S, G, F) * 0.1).astype(np.float32)
+    if ignore:
+        w[:, :, G - ignore:, :] = 0.0
+    lim = k // 2 - 0.01
+    mu1 = np.clip(rs.uniform(-m, m, (1, S, G, F)), -lim, lim).astype(np.float32)
+    mu2 = np.clip(rs.uniform(-m, m, (1, S, G, F)), -lim, lim).astype(np.float32)
+    return x, dy, w, mu1, mu2
+
+
+def run_plan(plan, x, dy, w, mu1, mu2, dtype=None, calls=1, sigma=0.5):
+    """forward + backward through the C ABI (status checked after every call) -> dict of the six tensors as numpy fp32."""
+    import torch
+    dtype = dtype or torch.float32
+    dev = lambda a: torch.from_numpy(a).cuda()
+    S, G, F = w.shape[1:]
+    sg = torch.full((1, S, G, F), float(sigma), device="cuda")
+    xd, dyd = dev(x).to(dtype), dev(dy).to(dtype)
+    wd, m1, m2 = dev(w), dev(mu1), dev(mu2)
+    for _ in range(calls):
+        y = plan.forward(xd, wd, m1, m2, sg)
+        plan.check_status()
+        g = plan.backward(xd, dyd, wd, m1, m2, sg)
+        plan.check_status()
+    torch.cuda.synchronize()
+    return dict(y=y.float().cpu().numpy(), dx=g[0].float().cpu().numpy(), dw=g[1].cpu().numpy(), dmu1=g[2].cpu().numpy(),
+                dmu2=g[3].cpu().numpy(), dsigma=g[4].cpu().numpy())
+
+
+def margins(got, want):
+    """{tensor: max|got - want| / max|want|} -- what a parity test prints so that the distance to its bar is on record."""
+    out = {}
+    for key in want:
+        w_ = np.asarray(want[key], np.float64)
+        out[key] = float(np.abs(np.asarray(got[key], np.float64) - w_).max() / max(np.abs(w_).max(), 1e-300))
+    return out
+
+
+_TUNING = []
+
+
+def tuning_capi():
+    """A second instance of the ctypes binding, over libdau_conv_hip_tuning.so (`make tuning`: the same sources with
+    -DDAU_TUNING).  Only that build reads the variant-pinning environment variables (DAU_GATHER_VARIANT, DAU_DOT_RW, ...), which the
+    variant tests use to run the kernels production picks for large batches on shapes the oracle finishes in seconds."""
+    if not _TUNING:
+        import importlib.util
+        pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dau-convnet_amd", "dau_conv")
+        so = os.path.join(pkg, "libdau_conv_hip_tuning.so")
+        assert os.path.exists(so), "%s missing: run `make -C dau-convnet_amd/csrc tuning` (or __graft_entry__.build())" % so
+        spec = importlib.util.spec_from_file_location("dau_conv_capi_tuning", os.path.join(pkg, "_capi.py"))
+        mod = importlib.util.module_from_spec(spec)
+        old = os.environ.get("DAU_CONV_LIB")
+        os.environ["DAU_CONV_LIB"] = so
+        try:
+            spec.loader.exec_module(mod)
+        finally:
+            if old is None:
+                del os.environ["DAU_CONV_LIB"]
+            else:
+                os.environ["DAU_CONV_LIB"] = old
+        _TUNING.append(mod)
+    return _TUNING[0]

@@ -1,6 +1,8 @@
 #!/bin/bash
 # per-kernel averages (rocprofv3 --stats) of one bench.py run under each given environment setting:
 #   tools/ab_env_prof.sh "<bench args>" "<kernel name substring>" "VAR=a" "VAR=b" ...
+# the environment knobs exist in the tuning build only (make -C dau-convnet_amd/csrc tuning)
+export DAU_CONV_LIB=${DAU_CONV_LIB:-${GRAFT_REPO_ROOT:-$PWD}/dau-convnet_amd/dau_conv/libdau_conv_hip_tuning.so}
 ARGS=$1; PAT=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 i=0

@@ -9,7 +9,7 @@ cd "$GRAFT_REPO_ROOT/dau-convnet_amd/csrc"
 make -s -j8 >/dev/null 2>&1
 mkdir -p ../../build/diag_FUSED
 /opt/rocm/bin/hipcc -O3 -std=c++20 -fPIC --offload-arch=gfx950 -I../../include -I. -fvisibility=hidden -DDAU_DIAG_FUSED_BLUR -c k_gather_mfma.hip -o /tmp/k_gm_fused.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/diag_FUSED/libdau_conv_hip.so dau_conv_api.o k_filters.o k_units.o k_direct.o /tmp/k_gm_fused.o k_gather_dot.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/diag_FUSED/libdau_conv_hip.so dau_conv_api.o k_filters.o k_units.o k_direct.o /tmp/k_gm_fused.o k_gather_dot.o k_dense_bf16.o k_dense_wgrad.o
 cd "$GRAFT_REPO_ROOT"
 for r in 1 2; do
   for L in dau-convnet_amd/dau_conv build/diag_FUSED; do

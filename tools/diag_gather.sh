@@ -4,15 +4,15 @@
 # Run on the GPU box from the repo root (builds the variants with hipcc first).
 set -e
 cd "$GRAFT_REPO_ROOT/dau-convnet_amd/csrc"
-make -s -j8 >/dev/null 2>&1
+make -s -j8 tuning >/dev/null 2>&1
 for V in NOLDS NOBARRIER "NOLDS -DDAU_DIAG_NOBARRIER"; do
   T=$(echo $V | tr -d ' -')
   mkdir -p ../../build/diag_$T
-  /opt/rocm/bin/hipcc -O3 -std=c++20 -fPIC --offload-arch=gfx950 -I../../include -I. -fvisibility=hidden -DDAU_DIAG_$V -c k_gather_mfma.hip -o /tmp/k_gm_$T.o 2>/dev/null
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/diag_$T/libdau_conv_hip.so dau_conv_api.o k_filters.o k_units.o k_direct.o /tmp/k_gm_$T.o k_gather_dot.o
+  /opt/rocm/bin/hipcc -O3 -std=c++20 -fPIC --offload-arch=gfx950 -I../../include -I. -fvisibility=hidden -DDAU_TUNING -DDAU_DIAG_$V -c k_gather_mfma.hip -o /tmp/k_gm_$T.o 2>/dev/null
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/diag_$T/libdau_conv_hip.so tuning_dau_conv_api.o tuning_k_filters.o tuning_k_units.o tuning_k_direct.o /tmp/k_gm_$T.o tuning_k_gather_dot.o tuning_k_dense_bf16.o tuning_k_dense_wgrad.o
 done
-cd "$GRAFT_REPO_ROOT"
-for L in dau-convnet_amd/dau_conv build/diag_NOLDS build/diag_NOBARRIER build/diag_NOLDSDDAU_DIAG_NOBARRIER; do
+mkdir -p build/diag_base 2>/dev/null; cd "$GRAFT_REPO_ROOT"; mkdir -p build/diag_base; cp dau-convnet_amd/dau_conv/libdau_conv_hip_tuning.so build/diag_base/libdau_conv_hip.so
+for L in build/diag_base build/diag_NOLDS build/diag_NOBARRIER build/diag_NOLDSDDAU_DIAG_NOBARRIER; do
   for D in 0 1; do
     DAU_CONV_LIB=$GRAFT_REPO_ROOT/$L/libdau_conv_hip.so DAU_GATHER_DEBUG=$D timeout -k 10 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | \
       python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$L debug=$D', d['roofline']['kernels']['gather_sum_fwd']['avg_ms'], d['roofline']['kernels']['gather_sum_dx']['avg_ms'])"
