@@ -23,8 +23,12 @@
 //    to all blocks (CBSZ/ABID), D register k of a lane = its gradient kind k.
 //  * A workgroup owns (32 output channels, a block of input channels, a block of four units) and walks (image pair,
 //    8x8 region) items with the LDS error tile filled by global_load_lds (two tiles for bucket 4, one for bucket 8).
-//    Buckets 16/32 run as 4/16 offset-window passes of the bucket-8 tile (units outside the window are zeroed).
+//    Buckets beyond 8 run as offset-window passes over a WORK LIST of half-sweeps (dot_worklist_kernel below).
 //    Work is split in chunks over the items; a small deterministic pass sums the partials (no float atomics).
+//  * Accuracy: a lane's fp32 accumulators take at most ~512 products; then they are added, in DOUBLE, to the workgroup's own
+//    slot of the partial sums (kFlushTerms below) and start again from zero.  The rounding error of a parameter gradient --
+//    a sum of N*H*W signed products -- therefore does not grow with the batch, the map size or the chunking (measured
+//    before: 1.4e-6 of the max-norm at 4 x 512 x 512, against the 1e-6 floor of SURVEY.md 8d).
 //  Tuning knobs (timing experiments only): -DDAU_DOT_WAVES=8, DAU_DOT_NBUF=1, DAU_DOT_AS1, DAU_DOT_DEBUG.
 #include <cstdlib>
 #include <type_traits>
@@ -68,9 +72,11 @@ struct DotGeometry {
     // The units of a channel are covered by up to two kernel passes: blocks of four units (two unit pairs per wave, two
     // input channels per wave) and, for a remainder of one or two units, one unit pair per wave with four input channels
     // per wave -- every wave carries four (channel, pair) slots either way.  A remainder of three takes a four-unit block.
-    // Several offset windows (R > 8, "binned"): one pass with one SLOT pair per wave and four input channels per wave;
-    // the units of (s, f) that fall into a window are compacted into slots 0, 1, ... of that window, ngb = slot pairs.
+    // Several offset windows (R > 8, "binned"): one pass over the WORK LIST of every (window, fb, channel group)
+    // (dot_worklist_kernel): AS = 4 entries per wave and round, ngb = rounds allocated, nsb = channel groups.
     struct Pass { int g_begin, GP, AS, ngb, sblock, nsb, chunks; size_t params_off, params_bytes; };
+    int sgroup;                 // binned: input channels per channel group (their Xk planes span less than 2 GiB, so that a
+                                // lane's channel offset fits the 32-bit VGPR offset of a global load); 0: shape not supported
     int npass;
     Pass pass[2];
     int nbuf;                   // error tiles resident in LDS: 2 (load under compute) or 1 (R = 8: one tile fills the LDS)
@@ -84,6 +90,9 @@ struct DotGeometry {
 };
 
 // as1 / one_tile: tuning choices fixed at plan creation (TiledDotConfig), so that every later call sees the same layout
+constexpr int kWlEntries = 4;                              // work list: entries per wave and round = AS of the binned gather-dot
+constexpr int kWlSlots = kDWaves * 2 * kWlEntries;         // half-sweeps per round
+
 DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one_tile = false, int rounds = 0, bool rw8 = false) {
     DotGeometry g{};
     // Bucket 18 (offsets within +-18: BASELINE config 4 has +-17): 2 x 2 windows of radius 9 over regions of 4 x 8
@@ -97,7 +106,10 @@ DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one
     const bool binned = g.nsub1 > 1;
     // rows per region: 7 when that pads the height less (7, 14, 21, 27, 28, ...)
     g.RW = kRW;
-    g.RH = wide ? 4 : (((sh.H + 6) / 7) * 7 < ((sh.H + 7) / 8) * 8 ? 7 : 8);
+    // window passes: regions of 4 rows x 8 columns -- one Xk load per region row and half wave, a ring of four loads (with 8 rows
+    // the ring alone would take 16 registers of a kernel that has none to spare); the tile is a ring of rows, an item loads 4 new
+    // rows whatever the region height, so nothing is lost but a barrier per 32 positions instead of 64
+    g.RH = binned ? 4 : (((sh.H + 6) / 7) * 7 < ((sh.H + 7) / 8) * 8 ? 7 : 8);
     {
         // 14 x 4 regions (same 56 positions as 8 x 7; a 13 x 23 tile, two of them fit the LDS) where they pad the map less:
         // 27 and 28 pixel maps become 28 x 28 instead of 28 x 32 positions.  Bucket 4 only (a bucket 8 tile would not fit),
@@ -123,13 +135,19 @@ DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one
         const int blocks4 = full4 + (rem == 3 ? 1 : 0);
         g.npass = 0;
         if (binned) {
-            g.pass[g.npass++] = DotGeometry::Pass{0, 1, 4, (sh.G + 1) / 2, 0, 0, 0, 0, 0};
+            const size_t plane_bytes = (size_t)g.Hp * g.Wp * 32;
+            const long fit = (long)(((size_t)1 << 31) / plane_bytes) / 32 * 32;          // whole tiles of 32 channels
+            g.sgroup = fit >= 32 ? (int)(fit < (sh.S + 31) / 32 * 32 ? fit : (sh.S + 31) / 32 * 32) : 0;
+            const int nsg = g.sgroup ? (sh.S + g.sgroup - 1) / g.sgroup : 1;
+            // every input channel of a group needs at most G half-sweeps
+            const int rounds_max = ((g.sgroup ? g.sgroup : 32) * sh.G + kWlSlots - 1) / kWlSlots;
+            g.pass[g.npass++] = DotGeometry::Pass{0, 1, kWlEntries, rounds_max, 0, nsg, 0, 0, 0};
         } else {
             if (blocks4 > 0) g.pass[g.npass++] = DotGeometry::Pass{0, 2, as1 ? 1 : 2, blocks4, 0, 0, 0, 0, 0};
             if (rem == 1 || rem == 2) g.pass[g.npass++] = DotGeometry::Pass{4 * full4, 1, 4, 1, 0, 0, 0, 0, 0};
         }
-        g.s_pad = 0;
-        for (int i = 0; i < g.npass; ++i) {
+        g.s_pad = binned ? sh.S : 0;
+        for (int i = 0; i < g.npass && !binned; ++i) {
             DotGeometry::Pass& ps = g.pass[i];
             ps.sblock = kDWaves * ps.AS;
             ps.nsb = (sh.S + ps.sblock - 1) / ps.sblock;
@@ -139,7 +157,8 @@ DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one
         for (int i = 0; i < g.npass; ++i) {
             DotGeometry::Pass& ps = g.pass[i];
             ps.params_off = off;
-            ps.params_bytes = round_up((size_t)g.nsub1 * g.nsub1 * g.s_pad * ps.ngb * ps.GP * g.nfb * 64 * kParamDwords * 4, 256);   // binned: ngb = slot pairs
+            ps.params_bytes = binned ? round_up((size_t)g.nsub1 * g.nsub1 * g.nfb * ps.nsb * ps.ngb * kWlSlots * 32 * kParamDwords * 4, 256)
+                                     : round_up((size_t)g.nsub1 * g.nsub1 * g.s_pad * ps.ngb * ps.GP * g.nfb * 64 * kParamDwords * 4, 256);
             off += ps.params_bytes;
         }
     }
@@ -149,17 +168,22 @@ DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one
     for (int i = 0; i < g.npass; ++i) {
         // at most four full rounds of 256 workgroups (one more workgroup would add a whole, nearly empty round), no
         // more chunks than items, and no chunk without items
-        // binned: most workgroups beyond the first slot pair find no unit and leave at once; the grid is sized for about
-        // one and a half busy slot pairs per (window, channel block) and eight rounds, so that light and heavy workgroups
-        // even out
-        const int per_chunk = binned ? g.nfb * g.pass[i].nsb * g.nsub1 * g.nsub1 * 3 / 2 : g.nfb * g.pass[i].nsb * g.pass[i].ngb;
-        // rounds: workgroups per CU the grid is sized for.  More chunks = shorter fp32 accumulation chains (every chunk's
-        // partial sums are added in double afterwards) and a finer tail, at 16 B of partial sums per unit and chunk; at the
-        // north-star shape 4, 8 and 16 rounds take the same time (same-box A/B, profiles/r2_ab_dot_rounds.txt), and 16
-        // rounds halve the rounding error of the parameter gradients against the double-accumulating oracle.
-        const int nrounds = rounds > 0 ? rounds : (binned ? 8 : 16);
+        // binned: the rounds a work list really uses depend on the offsets (the others leave at once); the grid is sized for
+        // the evenly spread case -- an input channel needs its mean number of units per (window, output channel), rounded up, as
+        // half-sweeps -- and for 32 busy workgroups per CU, so that the tail of the last workgroups stays short
+        int per_chunk = g.nfb * g.pass[i].nsb * g.pass[i].ngb;
+        if (binned) {
+            const double per_s = (double)sh.G / (g.nsub1 * g.nsub1) + 1.0;   // half-sweeps of 32 units per input channel
+            const int est = (int)((g.sgroup ? g.sgroup : 32) * (per_s < sh.G ? per_s : sh.G) / kWlSlots) + 1;
+            per_chunk = g.nfb * g.pass[i].nsb * g.nsub1 * g.nsub1 * est;
+        }
+        // rounds: workgroups per CU the grid is sized for.  More chunks = a finer tail, at 32 B of partial sums (double) per
+        // unit and chunk; at the north-star shape 4, 8 and 16 rounds take the same time (same-box A/B,
+        // profiles/r2_ab_dot_rounds.txt).  (Round 2 used 16 rounds to shorten the fp32 chains; the in-kernel flush to the
+        // double partial sums has taken that role.)
+        const int nrounds = rounds > 0 ? rounds : (binned ? 32 : 8);
         int chunks = (256 * nrounds + (binned ? per_chunk - 1 : 0)) / per_chunk;
-        if (!binned && chunks > 64) chunks = 64;            // the reduction pass reads every chunk's slab: keep it cheap on small layers
+        if (!binned && chunks > 32) chunks = 32;            // the reduction pass reads every chunk's slab: keep it cheap on small layers
         if (chunks > g.items) chunks = g.items;
         if (chunks < 1) chunks = 1;
         const int per = (g.items + chunks - 1) / chunks;
@@ -390,56 +414,110 @@ __global__ void dot_params_kernel(const UnitRef* __restrict__ table, int S, int 
     }
 }
 
-// Binned form (several offset windows): params[sub][s][slot pair][fb][lane][8] = {b00, b01, b10, b11, base, g, 0, 0} with
-// lane = (slot & 1)*32 + fl.  The units g of (s, f) whose offsets fall into window `sub` take the slots 0, 1, ... of that
-// window in ascending g; empty slots carry g = -1 and zero factors.  Every unit sits in exactly one (window, slot), so a
-// window pass of the gather-dot visits only its own units (round 1 visited all of them in every window with zeroed
-// factors; the reference splits its large-offset kernels by K instead, dau_conv_backward.cpp:194-231).  Units whose
-// factors are all zero (ignored units) take no slot.  One thread per (window, s, fb, fl).
-__global__ void dot_params_binned_kernel(const UnitRef* __restrict__ table, int S, int G, int F, int R, int Rt, int nsub1,
-                                         int epitch, int nsp, int nfb, int s_pad, float* __restrict__ params,
-                                         const Guard guard) {
+// Window passes (several offset windows, "binned"): the WORK LIST.
+// A sweep of the gather-dot gives every lane one unit; which unit is the lane's own business: its parameters carry the byte
+// address of its error column (output channel included), its bilinear factors and the index of the sum it accumulates.  What
+// the lanes of a HALF wave must share is the input channel s: the 4x4x1 MFMA broadcasts its A operand (Xk of a position) per
+// group of 8 blocks with CBSZ = 3 (tools/microbench/mfma_abid checks that), so the two half waves of a wave are independent.
+// So the units of (window, 32 output channels fb, input channel s) -- n_s of them, any number per output channel -- are dealt
+// into H_s = ceil(n_s / 32) HALF-SWEEPS of up to 32 units, round robin in (output channel, unit) order, so that the units of
+// one output channel go to different half-sweeps as far as possible: a half-sweep reads every LDS bank pair at most
+// ceil(count / H_s) times (two units of one output channel in a half-sweep = a two-way bank conflict on their ds_read_b64:
+// LDS cycles the kernel has to spare -- the LDS pipe was 28 % busy --, no wasted lanes).  Round 2 kept lane = output channel
+// (conflict-free reads): an input channel then needs max_f count(s, f) sweeps of 2 x 32 lanes however few of them are used
+// -- 13.0 sweeps per wave and item on BASELINE config 4's uniform offsets against 5.7 here and an ideal of 4.5
+// (tools/slot_histogram.py; the reference splits its large-offset kernels by K instead, dau_conv_backward.cpp:194-231).
+// The half-sweeps of a (window, fb, channel group) are listed in ascending s and dealt out: half-sweep h -> round h / 128, and
+// inside the round wave-half h % 32, entry (h % 128) / 32 -- every wave of every round but the last carries 4 full entries.
+//   params[sub][fb][sg][round][wave][entry][lane][8] = {b00, b01, b10, b11, base, u, soff, 0}
+//   base = byte address of the unit's error column in the tile (its output channel included); u = flat unit index
+//   (s*G + g)*F + f, -1 for an empty lane; soff = byte offset of channel s inside its group's Xk planes.
+//   nrounds[(sub*nfb + fb)*nsg + sg] = rounds in use (workgroups of later rounds leave at once).
+// Units whose factors are all zero (ignored units) take no slot.  One workgroup per (window, fb, channel group), 32 channels x
+// 32 output channels at a time.
+__global__ void __launch_bounds__(1024) dot_worklist_kernel(const UnitRef* __restrict__ table, int S, int G, int F, int R, int Rt,
+                                                            int nsub1, int epitch, int nfb, int nsg, int sgroup, int rounds_max,
+                                                            unsigned plane_bytes, float* __restrict__ params,
+                                                            int* __restrict__ nrounds, const Guard guard) {
     if (!guard_pass(guard)) return;
-    const long total = (long)nsub1 * nsub1 * s_pad * nfb * kDF;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int fl = (int)(idx % kDF);
-        long t = idx / kDF;
-        const int fb = (int)(t % nfb); t /= nfb;
-        const int s = (int)(t % s_pad);
-        const int sub = (int)(t / s_pad);
-        const int f = fb * kDF + fl;
-        const int cy = -R + Rt + 2 * Rt * (sub / nsub1), cx = -R + Rt + 2 * Rt * (sub % nsub1);
-        auto slot_ptr = [&](int slot) {
-            return params + ((((((long)sub * s_pad + s) * nsp + (slot >> 1)) * nfb + fb) * 64) + (slot & 1) * kDF + fl) * kParamDwords;
-        };
-        int cnt = 0;
-        if (s < S && f < F) {
-            for (int g = 0; g < G; ++g) {
-                const UnitRef u = table[((long)s * G + g) * F + f];
-                int wy = (u.oy + R) / (2 * Rt), wx = (u.ox + R) / (2 * Rt);
-                wy = wy < nsub1 ? wy : nsub1 - 1; wx = wx < nsub1 ? wx : nsub1 - 1;
-                if (wy != sub / nsub1 || wx != sub % nsub1) continue;
-                if (u.w00 == 0.0f && u.w01 == 0.0f && u.w10 == 0.0f && u.w11 == 0.0f) continue;
-                const int base = (((Rt - (u.oy - cy)) * epitch + (Rt - (u.ox - cx))) * kDF + fl) * 8;
-                float* dst = slot_ptr(cnt++);
-                dst[0] = u.w00; dst[1] = u.w01; dst[2] = u.w10; dst[3] = u.w11;
-                dst[4] = __int_as_float(base); dst[5] = __int_as_float(g); dst[6] = 0.0f; dst[7] = 0.0f;
-            }
+    __shared__ int K[32], pre[32], hbase;
+    int t = blockIdx.x;
+    const int sg = t % nsg; t /= nsg;
+    const int fb = t % nfb;
+    const int sub = t / nfb;
+    const int fl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int f = fb * kDF + fl;
+    const int cy = -R + Rt + 2 * Rt * (sub / nsub1), cx = -R + Rt + 2 * Rt * (sub % nsub1);
+    float* const pbase = params + (size_t)blockIdx.x * rounds_max * kWlSlots * 32 * kParamDwords;
+    auto slot_ptr = [&](int h, int ln) -> float* {         // lane ln of half-sweep h
+        const int round = h / kWlSlots, hl = h % kWlSlots;
+        const int wh = hl % (2 * kDWaves), entry = hl / (2 * kDWaves);
+        return pbase + ((((size_t)round * kDWaves + (wh >> 1)) * kWlEntries + entry) * 64 + (wh & 1) * 32 + ln) * kParamDwords;
+    };
+    auto in_window = [&](const UnitRef& u) {
+        int wy = (u.oy + R) / (2 * Rt), wx = (u.ox + R) / (2 * Rt);
+        wy = wy < nsub1 ? wy : nsub1 - 1; wx = wx < nsub1 ? wx : nsub1 - 1;
+        return wy == sub / nsub1 && wx == sub % nsub1 && !(u.w00 == 0.0f && u.w01 == 0.0f && u.w10 == 0.0f && u.w11 == 0.0f);
+    };
+    auto write_empty = [&](float* dst, unsigned soff) {    // (gathers from its own bank pair at the window centre, zero factors)
+        dst[0] = 0.0f; dst[1] = 0.0f; dst[2] = 0.0f; dst[3] = 0.0f;
+        dst[4] = __int_as_float(((Rt * epitch + Rt) * kDF + fl) * 8); dst[5] = __int_as_float(-1); dst[6] = __uint_as_float(soff); dst[7] = 0.0f;
+    };
+    if (threadIdx.x == 0) hbase = 0;
+    const int s_lo = sg * sgroup, s_hi = s_lo + sgroup < S ? s_lo + sgroup : S;
+    for (int s0 = s_lo; s0 < s_hi; s0 += 32) {
+        const int s = s0 + sl;                              // the 32 threads of a channel are one half wave
+        const bool live = s < s_hi && f < F;
+        int c = 0;
+        if (live)
+            for (int g = 0; g < G; ++g) c += in_window(table[((long)s * G + g) * F + f]) ? 1 : 0;
+        // position of this output channel's first unit in the channel's (f, g) order, and the channel's total
+        int incl = c;
+        for (int m = 1; m < 32; m <<= 1) {
+            const int v = __shfl_up(incl, m, 32);
+            if (fl >= m) incl += v;
         }
-        const int base0 = ((Rt * epitch + Rt) * kDF + fl) * 8;
-        for (; cnt < 2 * nsp; ++cnt) {
-            float* dst = slot_ptr(cnt);
-            dst[0] = 0.0f; dst[1] = 0.0f; dst[2] = 0.0f; dst[3] = 0.0f;
-            dst[4] = __int_as_float(base0); dst[5] = __int_as_float(-1); dst[6] = 0.0f; dst[7] = 0.0f;
+        const int i0 = incl - c, ns = __shfl(incl, 31, 32);
+        const int hs_n = (ns + 31) / 32;                    // half-sweeps of this channel
+        if (fl == 0) K[sl] = s < s_hi ? hs_n : 0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int acc = hbase;
+            for (int i = 0; i < 32; ++i) { pre[i] = acc; acc += K[i]; }
+            hbase = acc;
         }
+        __syncthreads();
+        if (s < s_hi && hs_n > 0) {
+            const unsigned soff = (unsigned)(s - s_lo) * plane_bytes;
+            int i = i0;
+            if (live)
+                for (int g = 0; g < G; ++g) {
+                    const UnitRef u = table[((long)s * G + g) * F + f];
+                    if (!in_window(u)) continue;
+                    float* dst = slot_ptr(pre[sl] + i % hs_n, i / hs_n);     // unit i -> half-sweep i mod H_s, lane i / H_s
+                    ++i;
+                    const int base = (((Rt - (u.oy - cy)) * epitch + (Rt - (u.ox - cx))) * kDF + fl) * 8;
+                    dst[0] = u.w00; dst[1] = u.w01; dst[2] = u.w10; dst[3] = u.w11;
+                    dst[4] = __int_as_float(base); dst[5] = __int_as_float((int)(((long)s * G + g) * F + f));
+                    dst[6] = __uint_as_float(soff); dst[7] = 0.0f;
+                }
+            // lanes a half-sweep does not use: half-sweep hs holds the units hs, hs + H_s, ... < n_s
+            for (int hs = 0; hs < hs_n; ++hs)
+                if (fl >= (ns - hs + hs_n - 1) / hs_n) write_empty(slot_ptr(pre[sl] + hs, fl), soff);
+        }
+        __syncthreads();
     }
+    // the unused half-sweeps of the last round are empty (their lanes gather from channel 0 of the group with zero factors)
+    const int total = hbase, rounds = (total + kWlSlots - 1) / kWlSlots;
+    for (int h = total + sl; h < rounds * kWlSlots; h += 32) write_empty(slot_ptr(h, fl), 0u);
+    if (threadIdx.x == 0) nrounds[blockIdx.x] = rounds;
 }
 
 // r4[k][u] = sum over the slabs of partial[slab][k][u]; units g < g_split were written by a pass with slabs0 slabs,
 // the others by a pass with slabs1 (u = (s*G + g)*F + f)
 // zero_from: units g >= zero_from have no partial sums (binned passes give ignored units no slot): their sums are zero
 // accumulate: add to r4 (second and later batch slabs of a call) instead of overwriting it
-__global__ void dot_reduce_kernel(const float* __restrict__ partial, long n, int G, int F, int g_split, int slabs0,
+__global__ void dot_reduce_kernel(const double* __restrict__ partial, long n, int G, int F, int g_split, int slabs0,
                                   int slabs1, int zero_from, int accumulate, float* __restrict__ r4, const Guard guard) {
     if (!guard_pass(guard)) return;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -447,7 +525,7 @@ __global__ void dot_reduce_kernel(const float* __restrict__ partial, long n, int
         const int slabs = g < g_split ? slabs0 : slabs1;
         double s = 0.0;
         if (g < zero_from)
-            for (int c = 0; c < slabs; ++c) s += (double)partial[(long)c * n + i];
+            for (int c = 0; c < slabs; ++c) s += partial[(long)c * n + i];
         r4[i] = accumulate ? (float)((double)r4[i] + s) : (float)s;
     }
 }
@@ -459,10 +537,12 @@ struct DotArgs {
     const char* ep;
     const float* xk;
     const float* params;
-    float* partial;
+    double* partial;            // [chunk][4][S][G][F]: every (chunk, unit) belongs to exactly one workgroup, which accumulates into it
     int N, S, F, G, R;
     int g_begin;                // first unit of this pass
-    int NP, nfb, nsb, ngb, nbuf, chunks, items;
+    int NP, nfb, nsb, ngb, nbuf, chunks, items;   // window passes (work list): nsb = channel groups, ngb = rounds allocated
+    const int* nrounds;         // window passes: rounds in use per (window, fb, channel group)
+    int sgroup;                 // window passes: input channels per channel group
     int Rt, nsub1;
     int rx, ry, EX, EY, Hp, Wp, epitch, erows, s_pad;
     unsigned tile_bytes;
@@ -499,23 +579,34 @@ __device__ __forceinline__ void lgkm_wait0() {
 
 // v_mfma_f32_4x4x1 with CBSZ = 4: the A operand of block ABID (lanes 4*ABID .. 4*ABID+3) feeds all 16 blocks
 // (checked on the hardware by tools/microbench/mfma_abid.hip).  abid is a constant after unrolling; the switch folds.
-template <int ABID>
-__device__ __forceinline__ f4 mfma_abid(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 4, ABID, 0); }
+// CBSZ = 3: two groups of 8 blocks (the two half waves), each fed by block ABID (< 8) of its own group.
+template <int CBSZ, int ABID>
+__device__ __forceinline__ f4 mfma_abid(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, CBSZ, ABID, 0); }
+template <int CBSZ>
 __device__ __forceinline__ f4 mfma_bcast(float a, float b, f4 c, int abid) {
-    switch (abid) {
-        case 0: return mfma_abid<0>(a, b, c);   case 1: return mfma_abid<1>(a, b, c);   case 2: return mfma_abid<2>(a, b, c);
-        case 3: return mfma_abid<3>(a, b, c);   case 4: return mfma_abid<4>(a, b, c);   case 5: return mfma_abid<5>(a, b, c);
-        case 6: return mfma_abid<6>(a, b, c);   case 7: return mfma_abid<7>(a, b, c);   case 8: return mfma_abid<8>(a, b, c);
-        case 9: return mfma_abid<9>(a, b, c);   case 10: return mfma_abid<10>(a, b, c); case 11: return mfma_abid<11>(a, b, c);
-        case 12: return mfma_abid<12>(a, b, c); case 13: return mfma_abid<13>(a, b, c); case 14: return mfma_abid<14>(a, b, c);
-        default: return mfma_abid<15>(a, b, c);
+    if constexpr (CBSZ == 3) {
+        switch (abid) {
+            case 0: return mfma_abid<3, 0>(a, b, c);   case 1: return mfma_abid<3, 1>(a, b, c);   case 2: return mfma_abid<3, 2>(a, b, c);
+            case 3: return mfma_abid<3, 3>(a, b, c);   case 4: return mfma_abid<3, 4>(a, b, c);   case 5: return mfma_abid<3, 5>(a, b, c);
+            case 6: return mfma_abid<3, 6>(a, b, c);   default: return mfma_abid<3, 7>(a, b, c);
+        }
+    } else {
+        switch (abid) {
+            case 0: return mfma_abid<4, 0>(a, b, c);   case 1: return mfma_abid<4, 1>(a, b, c);   case 2: return mfma_abid<4, 2>(a, b, c);
+            case 3: return mfma_abid<4, 3>(a, b, c);   case 4: return mfma_abid<4, 4>(a, b, c);   case 5: return mfma_abid<4, 5>(a, b, c);
+            case 6: return mfma_abid<4, 6>(a, b, c);   case 7: return mfma_abid<4, 7>(a, b, c);   case 8: return mfma_abid<4, 8>(a, b, c);
+            case 9: return mfma_abid<4, 9>(a, b, c);   case 10: return mfma_abid<4, 10>(a, b, c); case 11: return mfma_abid<4, 11>(a, b, c);
+            case 12: return mfma_abid<4, 12>(a, b, c); case 13: return mfma_abid<4, 13>(a, b, c); case 14: return mfma_abid<4, 14>(a, b, c);
+            default: return mfma_abid<4, 15>(a, b, c);
+        }
     }
 }
 
 // RH rows per region; the Xk ring has one slot per two region rows = 16 positions (the last slot of an odd RH fetches one
 // row too many, which is never used; the buffer has a spare row at its end)
-// BINNED: window pass over compacted unit slots (dot_params_binned_kernel): a lane's unit index comes with its
-// parameters, input channels whose slots are all empty are skipped by the wave, and a workgroup without any unit leaves.
+// BINNED: window pass over the work list (dot_worklist_kernel): a wave's AS entries are half-sweeps -- (input channel, k-th unit)
+// per HALF wave -- a lane's unit index and its half wave's Xk plane offset come with its parameters, empty entries are skipped
+// by the wave, and the workgroups of rounds the list does not use leave at once.
 // RW: columns per region (8, or 14 with RH = 4); the Xk ring has one slot per 16 positions of the region in row-major order
 // RING (window passes; one error tile fills the LDS): the items of a chunk walk DOWN the columns of regions and the tile is a
 // ring of rows, so that an item loads only the RH new rows of its tile (4 of 23 in bucket 18) instead of all of them.
@@ -523,7 +614,11 @@ template <int GP, int AS, int RH, bool BINNED = false, int RW = 8, bool RING = f
 __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) gather_dot_kernel(const DotArgs a) {
     constexpr int kRH = RH;
     constexpr int kRW = RW;                       // (shadows the namespace constant)
-    constexpr int kXSlots = RW == 8 ? (RH + 1) / 2 : (RH * RW + 15) / 16;
+    // positions one Xk load covers: 16 (lane 4b+i = kind i of position b of the wave's input channel), or -- window passes --
+    // 8 per half wave (lane 32h+4b+i = kind i of position b of half h's input channel): one region row
+    constexpr int kPPS = BINNED ? 8 : 16;
+    constexpr int kXSlots = BINNED ? RH : (RW == 8 ? (RH + 1) / 2 : (RH * RW + 15) / 16);
+    constexpr int kCBSZ = BINNED ? 3 : 4;            // A operand broadcast over all 16 blocks, or within each half wave
     static_assert(RW == 8 || (RW % 2 == 0 && !BINNED), "region width");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (!guard_pass(a.guard)) return;
@@ -539,8 +634,8 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
         const int chunk_ = nblk / 8, rem = nblk % 8;
         logical = (xcd < rem ? xcd * (chunk_ + 1) : rem * (chunk_ + 1) + (xcd - rem) * chunk_) + idx;
     }
-    const int sb = logical % a.nsb;
-    const int gb = (logical / a.nsb) % a.ngb;
+    const int sb = logical % a.nsb;                  // block of input channels (window passes: channel group)
+    const int gb = (logical / a.nsb) % a.ngb;        // block of units (window passes: round of the work list)
     const int fb = (logical / (a.nsb * a.ngb)) % a.nfb;
     const int nsub = a.nsub1 * a.nsub1;
     const int sub = (logical / (a.nsb * a.ngb * a.nfb)) % nsub;
@@ -548,6 +643,10 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     // tile origin of this pass's offset window inside the staged error plane (0 when one tile covers the bucket)
     const int sub_dy = 2 * (a.R - a.Rt) - 2 * a.Rt * (sub / a.nsub1), sub_dx = 2 * (a.R - a.Rt) - 2 * a.Rt * (sub % a.nsub1);
 
+    if constexpr (BINNED) {
+        // rounds beyond the ones the work list of this (window, fb, channel group) uses: nothing to do
+        if (gb >= a.nrounds[(sub * a.nfb + fb) * a.nsb + sb]) return;
+    }
     // this chunk's contiguous range of items (image pair, region)
     const int per = (a.items + a.chunks - 1) / a.chunks;
     const int item0 = chunk * per;
@@ -555,12 +654,12 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
 
     // per-lane parameters of the wave's AS x GP units, resident in registers for the whole kernel
     f2 bw[AS][GP][2];
-    unsigned base[AS][GP];
-    int brow[AS][GP];           // RING: the lane's first tile row (base then holds the offset inside a row)
-    int gidx[AS][GP];           // BINNED: the lane's unit g, -1 for an empty slot
+    unsigned base[AS][GP];      // RING: (the lane's first tile row) << 16 | byte offset inside a row
+    int gidx[AS][GP];           // BINNED: the lane's flat unit index (s*G + g)*F + f, -1 for an empty lane
+    unsigned xv[AS];            // BINNED: the lane's Xk offset: its half wave's input channel plane + (lane & 31) * 8
     int s_of[AS];
-    bool act[AS];               // BINNED: some lane of the wave has a unit of input channel si (wave-uniform)
-    const int s_base = sb * (kDWaves * AS) + wave * AS;
+    bool act[AS];               // BINNED: some lane of the wave has a unit in entry si (wave-uniform)
+    const int s_base = BINNED ? sb * a.sgroup : sb * (kDWaves * AS) + wave * AS;
 #pragma unroll
     for (int si = 0; si < AS; ++si) {
         const int s = s_base + si;
@@ -568,17 +667,19 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
         act[si] = true;
 #pragma unroll
         for (int gp = 0; gp < GP; ++gp) {
-            const float* p = a.params + ((((((long)sub * a.s_pad + s) * a.ngb + gb) * GP + gp) * a.nfb + fb) * 64 + lane) * kParamDwords;
+            const float* p = BINNED ? a.params + (((((((long)sub * a.nfb + fb) * a.nsb + sb) * a.ngb + gb) * kDWaves + wave) * AS + si) * 64 + lane) * kParamDwords
+                                    : a.params + ((((((long)sub * a.s_pad + s) * a.ngb + gb) * GP + gp) * a.nfb + fb) * 64 + lane) * kParamDwords;
             bw[si][gp][0] = f2{p[0], p[1]};
             bw[si][gp][1] = f2{p[2], p[3]};
             base[si][gp] = (unsigned)__float_as_int(p[4]);
             if constexpr (RING) {
                 // tile row and byte offset inside the row (the row lives in a ring slot that changes from item to item)
                 const unsigned rb = (unsigned)a.epitch * kDF * 8;
-                brow[si][gp] = (int)(base[si][gp] / rb);
-                base[si][gp] -= (unsigned)brow[si][gp] * rb;
+                const unsigned br = base[si][gp] / rb;
+                base[si][gp] = (br << 16) | (base[si][gp] - br * rb);       // a row is at most 27 positions x 256 B
             }
             gidx[si][gp] = BINNED ? __float_as_int(p[5]) : 0;
+            if constexpr (BINNED) xv[si] = __float_as_uint(p[6]) + (unsigned)(lane & 31) * 8u;
         }
         if constexpr (BINNED) {
             bool any = false;
@@ -592,15 +693,13 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
         first_act = AS;
 #pragma unroll
         for (int si = AS - 1; si >= 0; --si) first_act = act[si] ? si : first_act;
-        // this slot pair is empty for the whole (window, channel block, 64 input channels): nothing to do.  (The flag
-        // lives behind the error tiles in the dynamic LDS: __syncthreads_or would add static LDS on top of a tile that
-        // already takes all but 3 KiB of the 160.)
-        volatile unsigned* any_unit = reinterpret_cast<volatile unsigned*>(smem + (size_t)a.nbuf * a.tile_bytes);
-        if (threadIdx.x == 0) *any_unit = 0u;
-        __syncthreads();
-        if (lane == 0 && first_act < AS) *any_unit = 1u;
-        __syncthreads();
-        if (*any_unit == 0u) return;
+    }
+    // BINNED: the per-lane Xk offset of the first active entry.  (Selected by the act[] flags, here and for the next active
+    // entry below: a select chain keyed on the entry INDEX is turned into a dynamically indexed array by hipcc, i.e. scratch.)
+    unsigned xv_first = 0;
+    if constexpr (BINNED) {
+#pragma unroll
+        for (int si = AS - 1; si >= 0; --si) xv_first = act[si] ? xv[si] : xv_first;
     }
     const bool wave_idle = first_act >= AS;
 
@@ -687,8 +786,10 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
         xoff[t] = RW == 8 ? 0u : (unsigned)((P / kRW) * xpitch + (P % kRW) * 32 + (lane & 3) * 8);
     }
     // slot t of the sweep that starts at `base`
-    auto x_fetch = [&](f2& dst, const char* base, int t) {
-        if constexpr (RW == 8) x_load(dst, xlane, base + 2 * t * xpitch, 0);
+    // (window passes: `base` is the sweep origin in the channel group's first plane, voff the lane's channel + position offset)
+    auto x_fetch = [&](f2& dst, const char* base, int t, unsigned voff) {
+        if constexpr (BINNED) x_load(dst, voff, base + t * xpitch, 0);
+        else if constexpr (RW == 8) x_load(dst, xlane, base + 2 * t * xpitch, 0);
         else x_load(dst, xoff[t], base, 0);
     };
     auto sweep_ptr = [&](int item, int s) -> const char* {
@@ -709,12 +810,46 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     if (item0 < item1) {
         issue(item0, 0);
         if (!wave_idle) {
-            const char* x0 = sweep_ptr(item0, s_base + first_act);
+            const char* x0 = sweep_ptr(item0, BINNED ? s_base : s_base + first_act);
+            const unsigned v0 = xv_first;
 #pragma unroll
-            for (int i = 0; i < kXSlots; ++i) x_fetch(xr[i], x0, i);
+            for (int i = 0; i < kXSlots; ++i) x_fetch(xr[i], x0, i, v0);
         }
     }
+    // The fp32 accumulators leave for the (double) partial sums every kFlushItems items: ~1024 products per chain.
+    // partial[chunk][k][(s*G+g)*F+f] += image 0 + image 1.  Every unit is written by exactly one workgroup per chunk: its own
+    // (unit block) pass, or -- BINNED -- the pass of the one (window, slot) it was binned into; so this is a plain
+    // read-modify-write in a fixed order (deterministic, no atomics).  The first flush stores.
+    constexpr int kFlushTerms = 512;
+    constexpr int kFlushItems = kFlushTerms / (RH * RW) > 0 ? kFlushTerms / (RH * RW) : 1;
+    const long units = (long)a.S * a.G * a.F;
+    bool flushed = false;
+    auto flush = [&]() {
+        const int half = lane >> 5, f = fb * kDF + (lane & 31);
+#pragma unroll
+        for (int si = 0; si < AS; ++si)
+#pragma unroll
+            for (int gp = 0; gp < GP; ++gp) {
+                const int s = s_of[si], g = a.g_begin + gb * 2 * GP + 2 * gp + half;
+                // one entry at a time, its address computed here and now: the kernel has no registers to spare for sixteen
+                // loads in flight or for addresses hoisted out of the item loop (the empty asm pins the computation here)
+                int u = BINNED ? gidx[si][gp] : (s * a.G + g) * a.F + f;
+                asm volatile("" : "+v"(u));
+                if (BINNED ? u >= 0 : (s < a.S && g < a.G && f < a.F)) {
+                    double* dst = a.partial + (long)chunk * kNumK * units + u;
+#pragma unroll
+                    for (int kk = 0; kk < kNumK; ++kk) {
+                        const double v = (double)acc[si][gp][0][kk] + (double)acc[si][gp][1][kk];
+                        dst[kk * units] = flushed ? dst[kk * units] + v : v;
+                    }
+                }
+                acc[si][gp][0] = f4{0, 0, 0, 0}; acc[si][gp][1] = f4{0, 0, 0, 0};
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        flushed = true;
+    };
     int origin = 0;             // RING: ring slot of the current tile's row 0
+    int since_flush = 0;
     for (int item = item0; item < item1; ++item) {
         const bool two = a.nbuf == 2;
         const int buf = two ? (item - item0) & 1 : 0;
@@ -733,15 +868,20 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
 #pragma unroll
         for (int si = 0; si < AS; ++si) {
             if (BINNED && !act[si]) continue;     // wave-uniform: no unit of this input channel in the wave's slots
-            const char* xbase = sweep_ptr(item, s_of[si]);
+            const char* xbase = sweep_ptr(item, BINNED ? s_base : s_of[si]);
             // where the ring continues after this sweep: next input channel of this item (BINNED: the next one that
             // has units), or the next item (or, at the very end, the last row again so that the number of loads in
             // flight stays constant)
             int nxt = AS;
+            unsigned vnext = item + 1 < item1 ? xv_first : (BINNED ? xv[si] : 0u);
 #pragma unroll
-            for (int sj = AS - 1; sj > si; --sj) nxt = act[sj] ? sj : nxt;
-            const char* xnext_sweep = nxt < AS ? sweep_ptr(item, s_base + nxt)
-                                               : (item + 1 < item1 ? sweep_ptr(item + 1, s_base + first_act) : xbase);
+            for (int sj = AS - 1; sj > si; --sj) {
+                nxt = act[sj] ? sj : nxt;
+                if constexpr (BINNED) vnext = act[sj] ? xv[sj] : vnext;
+            }
+            const char* xnext_sweep = BINNED ? (nxt < AS || item + 1 >= item1 ? xbase : sweep_ptr(item + 1, s_base))
+                                             : nxt < AS ? sweep_ptr(item, s_base + nxt)
+                                                        : (item + 1 < item1 ? sweep_ptr(item + 1, s_base + first_act) : xbase);
 
             // The sweep over the 8x8 region is fully unrolled (no back-edge copies).  Software pipeline over groups
             // of two positions: at the END of a group one lgkmcnt(0) retires the error columns prefetched for the
@@ -754,18 +894,20 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
             unsigned rowaddr[GP], rowaddr2[GP];
             int slot2[GP];               // RING: ring slot of rowaddr2's tile row
             // address of the tile row below rowaddr2's
+            unsigned bcol[GP];           // RING: the lane's byte offset inside a tile row
             auto row_below = [&](int gp) -> unsigned {
-                if constexpr (RING) return slot2[gp] + 1 == a.erows ? base[si][gp] : rowaddr2[gp] + row_bytes;
+                if constexpr (RING) return slot2[gp] + 1 == a.erows ? bcol[gp] : rowaddr2[gp] + row_bytes;
                 else return rowaddr2[gp] + row_bytes;
             };
 #pragma unroll
             for (int gp = 0; gp < GP; ++gp) {
                 if constexpr (RING) {
-                    int sl = origin + brow[si][gp];
+                    bcol[gp] = base[si][gp] & 0xffffu;
+                    int sl = origin + (int)(base[si][gp] >> 16);
                     sl = sl >= a.erows ? sl - a.erows : sl;
-                    rowaddr[gp] = (unsigned)sl * row_bytes + base[si][gp];
+                    rowaddr[gp] = (unsigned)sl * row_bytes + bcol[gp];
                     slot2[gp] = sl + 1 == a.erows ? 0 : sl + 1;
-                    rowaddr2[gp] = (unsigned)slot2[gp] * row_bytes + base[si][gp];
+                    rowaddr2[gp] = (unsigned)slot2[gp] * row_bytes + bcol[gp];
                 } else {
                     rowaddr[gp] = base[si][gp] + bufoff;
                     rowaddr2[gp] = rowaddr[gp] + row_bytes;
@@ -869,7 +1011,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                     // Xk of this group's positions: when the group opens a new slot (16 positions), that slot is the oldest of
                     // the ring
                     const int pos0 = j * kRW + GS * gq;                   // first position of the group, row-major in the region
-                    if (RW == 8 ? (j % 2 == 0 && gq == 0) : (pos0 % 16 == 0)) {
+                    if (pos0 % kPPS == 0) {
                         if (!BINNED && si == 0 && two) x_wait<kXSlots - 1 + kRounds4>();
                         else x_wait<kXSlots - 1>();
                     }
@@ -880,9 +1022,9 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                     for (int p = 0; p < GS; ++p) {
 #pragma unroll
                         for (int gp = 0; gp < GP; ++gp) {
-                            const int abid = (pos0 + p) % 16, slot = (pos0 + p) / 16;     // position within the slot's 16
-                            acc[si][gp][0] = mfma_bcast(xr[slot].x, et[p][gp].x, acc[si][gp][0], abid);
-                            acc[si][gp][1] = mfma_bcast(xr[slot].y, et[p][gp].y, acc[si][gp][1], abid);
+                            const int abid = (pos0 + p) % kPPS, slot = (pos0 + p) / kPPS;     // position within the slot's 16 (8)
+                            acc[si][gp][0] = mfma_bcast<kCBSZ>(xr[slot].x, et[p][gp].x, acc[si][gp][0], abid);
+                            acc[si][gp][1] = mfma_bcast<kCBSZ>(xr[slot].y, et[p][gp].y, acc[si][gp][1], abid);
                         }
                     }
 #if DAU_DOT_PRIO
@@ -890,7 +1032,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                     // the slot is consumed: refill it with the same positions of the next sweep
-                    if ((pos0 + GS) % 16 == 0 || pos0 + GS == kRH * kRW) x_fetch(xr[pos0 / 16], xnext_sweep, pos0 / 16);
+                    if ((pos0 + GS) % kPPS == 0 || pos0 + GS == kRH * kRW) x_fetch(xr[pos0 / kPPS], xnext_sweep, pos0 / kPPS, vnext);
                     lgkm_wait0();   // the prefetched group has landed
                 }
                 // next row: tile rows shift down by one
@@ -919,25 +1061,12 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                 if (!(a.debug & 2)) issue(item + 1, 0);
             }
         }
+        if (++since_flush == kFlushItems && item + 1 < item1) { flush(); since_flush = 0; }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    // partial[chunk][k][(s*G+g)*F+f] = image 0 + image 1.  Every unit is written by exactly one workgroup per chunk:
-    // its own (unit block) pass, or -- BINNED -- the pass of the one (window, slot) it was binned into.
-    const long units = (long)a.S * a.G * a.F;
-    const int half = lane >> 5, f = fb * kDF + (lane & 31);
-#pragma unroll
-    for (int si = 0; si < AS; ++si)
-#pragma unroll
-        for (int gp = 0; gp < GP; ++gp) {
-            const int s = s_of[si], g = BINNED ? gidx[si][gp] : a.g_begin + gb * 2 * GP + 2 * gp + half;
-            if (s < a.S && g >= 0 && g < a.G && f < a.F) {
-                float* dst = a.partial + (long)chunk * kNumK * units + ((long)s * a.G + g) * a.F + f;
-#pragma unroll
-                for (int kk = 0; kk < kNumK; ++kk) dst[kk * units] = acc[si][gp][0][kk] + acc[si][gp][1][kk];
-            }
-        }
+    flush();
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -945,7 +1074,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
 namespace {
 
 struct DotLayout {
-    size_t ep_off, xk_off, params_off, partial_off, total;
+    size_t ep_off, xk_off, params_off, nrounds_off, partial_off, total;
 };
 
 DotLayout dot_layout(const TiledDotConfig& c, const DotGeometry& g) {
@@ -957,7 +1086,8 @@ DotLayout dot_layout(const TiledDotConfig& c, const DotGeometry& g) {
     l.xk_off = off; off += round_up(NP * s_pad * g.Hp * g.Wp * 32 + (size_t)g.Wp * 32, 256);   // + one spare row
     l.params_off = off;
     for (int i = 0; i < g.npass; ++i) off += g.pass[i].params_bytes;
-    l.partial_off = off; off += round_up((size_t)g.chunks * kNumK * c.sh.S * c.sh.G * c.sh.F * 4, 256);
+    l.nrounds_off = off; off += round_up((size_t)g.nsub1 * g.nsub1 * g.nfb * g.pass[0].nsb * 4, 256);   // work lists: rounds in use
+    l.partial_off = off; off += round_up((size_t)g.chunks * kNumK * c.sh.S * c.sh.G * c.sh.F * 8, 256);   // double
     l.total = off;
     return l;
 }
@@ -989,15 +1119,8 @@ void dispatch_dot(bool binned, bool ring, int RW, int RH, int GP, int AS, hipStr
     }
     if (binned) {
         // window passes: the tile is a ring of rows (DAU_DOT_RING=0 at plan creation: whole tiles, for A/B)
-        if (ring) {
-            if (RH == 8) launch_dot<1, 4, 8, true, 8, true>(st, a, grid, lds);
-            else if (RH == 4) launch_dot<1, 4, 4, true, 8, true>(st, a, grid, lds);
-            else launch_dot<1, 4, 7, true, 8, true>(st, a, grid, lds);
-            return;
-        }
-        if (RH == 8) launch_dot<1, 4, 8, true>(st, a, grid, lds);
-        else if (RH == 4) launch_dot<1, 4, 4, true>(st, a, grid, lds);
-        else launch_dot<1, 4, 7, true>(st, a, grid, lds);
+        if (ring) launch_dot<1, 4, 4, true, 8, true>(st, a, grid, lds);
+        else launch_dot<1, 4, 4, true>(st, a, grid, lds);
     } else if (RH == 8) {
         if (GP == 1) launch_dot<1, 4, 8>(st, a, grid, lds);
         else if (AS == 2) launch_dot<2, 2, 8>(st, a, grid, lds);
@@ -1050,7 +1173,8 @@ bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, int igno
     const int rounds = DAU_TUNE_INT("DAU_DOT_ROUNDS", 0);
     const bool rw8 = DAU_TUNE_INT("DAU_DOT_RW", 0) == 8;      // 8-column regions only (A/B of the 14 x 4 form)
     const DotGeometry g = make_dot_geometry(sh, R, as1, one_tile, rounds, rw8);
-    if (g.nbuf * g.tile_bytes + 16 > 160 * 1024) return false;
+    if (g.nbuf * g.tile_bytes > 160 * 1024) return false;
+    if (g.nsub1 > 1 && g.sgroup == 0) return false;          // one Xk plane of 2 GiB and more: maps beyond ~1400 x 1400
     // immediates of the unrolled column walk must fit 16 bits
     if ((size_t)g.epitch * kDF * 8 + (g.RW + 1) * kDF * 8 > 65535) return false;
     {
@@ -1096,10 +1220,9 @@ void tiled_dot_prepare(hipStream_t st, const TiledDotConfig& c, const float* x, 
     launch_blur4_pack(st, x, filters, s.N, s.S, s_pad, s.H, s.W, g.Hp, g.Wp, c.blur_k, c.bf16, reinterpret_cast<float*>(ws + l.xk_off), guard);
     if (g.nsub1 > 1) {
         const DotGeometry::Pass& ps = g.pass[0];
-        const long total = (long)g.nsub1 * g.nsub1 * s_pad * g.nfb * kDF;
-        const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-        hipLaunchKernelGGL(dot_params_binned_kernel, dim3(grid), dim3(256), 0, st, table_bare, s.S, s.G, s.F, g.Rp, g.Rt, g.nsub1,
-                           g.epitch, ps.ngb, g.nfb, s_pad, reinterpret_cast<float*>(ws + l.params_off + ps.params_off), guard);
+        hipLaunchKernelGGL(dot_worklist_kernel, dim3(g.nsub1 * g.nsub1 * g.nfb * ps.nsb), dim3(1024), 0, st, table_bare, s.S, s.G, s.F,
+                           g.Rp, g.Rt, g.nsub1, g.epitch, g.nfb, ps.nsb, g.sgroup, ps.ngb, (unsigned)((size_t)g.Hp * g.Wp * 32),
+                           reinterpret_cast<float*>(ws + l.params_off + ps.params_off), reinterpret_cast<int*>(ws + l.nrounds_off), guard);
         return;
     }
     for (int i = 0; i < g.npass; ++i) {
@@ -1120,16 +1243,18 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
     DotArgs a{};
     a.ep = ws + l.ep_off;
     a.xk = reinterpret_cast<const float*>(ws + l.xk_off);
-    a.partial = reinterpret_cast<float*>(ws + l.partial_off);
+    a.partial = reinterpret_cast<double*>(ws + l.partial_off);
     a.N = s.N; a.S = s.S; a.F = s.F; a.G = s.G; a.R = g.Rp;
     a.NP = c.NP; a.nfb = g.nfb; a.nbuf = g.nbuf; a.Rt = g.Rt; a.nsub1 = g.nsub1; a.chunks = g.chunks; a.items = g.items;
     a.rx = g.rx; a.ry = g.ry; a.EX = g.EX; a.EY = g.EY; a.Hp = g.Hp; a.Wp = g.Wp; a.epitch = g.epitch; a.erows = g.erows;
     a.s_pad = g.s_pad;
+    a.nrounds = reinterpret_cast<const int*>(ws + l.nrounds_off);
+    a.sgroup = g.sgroup;
     a.tile_bytes = (unsigned)g.tile_bytes;
     a.debug = c.debug;
     a.guard = guard;
     const bool binned = g.nsub1 > 1;
-    const size_t lds = (size_t)g.nbuf * g.tile_bytes + 16;   // + the "any unit" word of the binned kernel
+    const size_t lds = (size_t)g.nbuf * g.tile_bytes;
     for (int i = 0; i < g.npass; ++i) {           // every pass writes its own units' slabs of the partial sums
         const DotGeometry::Pass& ps = g.pass[i];
         a.params = reinterpret_cast<const float*>(ws + l.params_off + ps.params_off);

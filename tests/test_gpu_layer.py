@@ -212,7 +212,7 @@ def test_bad_offsets_of_a_middle_layer_are_not_overwritten_by_later_calls():
         plan = dc._get_plan(x, w, dc._settings(sigma, num_output=4, kernel_size=9))
         with pytest.raises(error):
             plan.last_status()
-        assert plan.last_status() == 0.0                   # reported once; the mirror is clean again
+        assert plan.last_status() is None                  # reported once; the mirror is back to "nothing to report"
         call(mu)
         dau_conv.check_pending_offsets()
     # the same through the default mode: the error surfaces on a later call although good calls ran in between

@@ -126,7 +126,7 @@ def test_unit_bookkeeping_bit_exact():
         # forward pass: premultiplied by w
         off, fac = plan.unit_table(_dev(mu1), _dev(mu2), w=_dev(w))
         assert np.array_equal(off.cpu().numpy(), eoff)
-        wl = (w * live).reshape(S, G, F, 1).astype(np.float32)
+        wl = np.where(live > 0, w, np.float32(0.0)).reshape(S, G, F, 1).astype(np.float32)   # an ignored unit's weight is +0
         want = wl * efac.reshape(S, G, F, 4)                                      # one fp32 multiply, as the kernel does
         assert np.array_equal(bits(fac.cpu().numpy()), bits(want.reshape(-1, 4)))
         # input-gradient pass: [F][G][S] order, offsets negated (floor(-mu), its own fractions), premultiplied by w; every

@@ -92,6 +92,18 @@ def margins(got, want):
     return out
 
 
+def record_margins(name, got, want, bar):
+    """Append {test, bar, max|got-want|/max|want| per tensor} to gpurun_out/parity_margins.jsonl (where the GPU box's scratch
+    directory exists): the distance of the big parity tests to their bars, kept under profiles/ per round."""
+    import json
+    m = margins(got, want)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_margins.jsonl"), "a") as fh:
+            fh.write(json.dumps(dict(test=name, bar=bar, max_err_over_max_norm={k: float("%.3e" % v) for k, v in m.items()})) + "\n")
+    return m
+
+
 _TUNING = []
 
 

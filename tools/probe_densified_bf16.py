@@ -49,17 +49,19 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "ns"])
     ap.add_argument("--images", type=int, default=128)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--radius", type=int, default=4, help="offset bucket R: 4 (kernel 9, 10 x 10 dense taps) or 8 (kernel 17, 18 x 18)")
+    ap.add_argument("--units", type=int, default=0, help="units per channel (default: the workload's)")
     args = ap.parse_args()
     from dau_conv import _capi
     from oracle import dau_oracle as orc
     dev = torch.device("cuda", 0)
-    N, S, F, H, W, R = args.images, 256, 256, 56, 56, 4
-    G = 6 if args.workload == "c2" else 4
+    N, S, F, H, W, R = args.images, 256, 256, 56, 56, args.radius
+    G = args.units or (6 if args.workload == "c2" else 4)
     g = torch.Generator(device=dev); g.manual_seed(7)
     x = torch.rand((N, S, H, W), device=dev, generator=g).to(torch.bfloat16)
     w = torch.randn((1, S, G, F), device=dev, generator=g) * 0.1
-    mu1 = ((torch.rand((1, S, G, F), device=dev, generator=g) * 2 - 1) * 3.0)
-    mu2 = ((torch.rand((1, S, G, F), device=dev, generator=g) * 2 - 1) * 3.0)
+    mu1 = ((torch.rand((1, S, G, F), device=dev, generator=g) * 2 - 1) * (R - 1.0))
+    mu2 = ((torch.rand((1, S, G, F), device=dev, generator=g) * 2 - 1) * (R - 1.0))
     sigma = torch.full((1, S, G, F), 0.5, device=dev)
 
     def timed(fn, steps):
@@ -74,7 +76,7 @@ def main():
         return e0.elapsed_time(e1) / steps, out
 
     # --- this repository: gather-sum on the fp32 matrix cores, bf16 activations in HBM -------------------------------
-    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5,
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=2 * R + 1, sigma_hint=0.5,
                       flags=_capi.FLAG_USE_INTERPOLATION | _capi.FLAG_IO_BF16)
     t_gather, y_gather = timed(lambda: plan.forward(x, w, mu1, mu2, sigma), args.steps)
     plan.profile_begin()
@@ -116,7 +118,7 @@ def main():
 
     gather_flops = 8.0 * G * N * H * W * S * F
     dense_flops = 2.0 * (2 * R + 2) ** 2 * N * H * W * S * F
-    out = dict(workload="%s: N=%d C=%d->%d HW=%d G=%d k=9, bf16 activations" % (args.workload, N, S, F, H, G),
+    out = dict(workload="%s: N=%d C=%d->%d HW=%d G=%d k=%d, bf16 activations" % (args.workload, N, S, F, H, G, 2 * R + 1),
                gather_sum_fp32_mfma=dict(ms_call=round(t_gather, 3), ms_kernel=round(t_gather_kernel, 3),
                                          tflops_algorithmic=round(gather_flops / (t_gather_kernel * 1e-3) / 1e12, 1),
                                          parity_violation=viol(y_gather)[0], err_rel_to_max=viol(y_gather)[1]),
