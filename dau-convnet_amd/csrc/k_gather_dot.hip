@@ -25,10 +25,11 @@
 //    8x8 region) items with the LDS error tile filled by global_load_lds (two tiles for bucket 4, one for bucket 8).
 //    Buckets beyond 8 run as offset-window passes over a WORK LIST of half-sweeps (dot_worklist_kernel below).
 //    Work is split in chunks over the items; a small deterministic pass sums the partials (no float atomics).
-//  * Accuracy: a lane's fp32 accumulators take at most ~512 products; then they are added, in DOUBLE, to the workgroup's own
+//  * Accuracy: a lane's fp32 accumulators take at most ~1024 products; then they are added, in DOUBLE, to the workgroup's own
 //    slot of the partial sums (kFlushTerms below) and start again from zero.  The rounding error of a parameter gradient --
-//    a sum of N*H*W signed products -- therefore does not grow with the batch, the map size or the chunking (measured
-//    before: 1.4e-6 of the max-norm at 4 x 512 x 512, against the 1e-6 floor of SURVEY.md 8d).
+//    a sum of N*H*W signed products -- therefore does not grow with the batch, the map size or the chunking: 6-7e-7 of the
+//    max-norm at every size measured (before: 1.4e-6 at 4 x 512 x 512; the floor of SURVEY.md 8d is 1e-6).  Cost at the
+//    north-star shape, same box: 17.17 ms without, 17.34 ms with a flush every 1024 products, 17.62 ms every 512 (4.5e-7).
 //  Tuning knobs (timing experiments only): -DDAU_DOT_WAVES=8, DAU_DOT_NBUF=1, DAU_DOT_AS1, DAU_DOT_DEBUG.
 #include <cstdlib>
 #include <type_traits>
@@ -106,10 +107,9 @@ DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one
     const bool binned = g.nsub1 > 1;
     // rows per region: 7 when that pads the height less (7, 14, 21, 27, 28, ...)
     g.RW = kRW;
-    // window passes: regions of 4 rows x 8 columns -- one Xk load per region row and half wave, a ring of four loads (with 8 rows
-    // the ring alone would take 16 registers of a kernel that has none to spare); the tile is a ring of rows, an item loads 4 new
-    // rows whatever the region height, so nothing is lost but a barrier per 32 positions instead of 64
-    g.RH = binned ? 4 : (((sh.H + 6) / 7) * 7 < ((sh.H + 7) / 8) * 8 ? 7 : 8);
+    // (bucket 18: regions of 4 rows x 8 columns, the most a radius-9 tile leaves room for)
+    // (window passes: 8 rows -- their Xk ring holds row r of a sweep in slot r % 4, which needs whole multiples of four rows)
+    g.RH = wide ? 4 : binned ? 8 : (((sh.H + 6) / 7) * 7 < ((sh.H + 7) / 8) * 8 ? 7 : 8);
     {
         // 14 x 4 regions (same 56 positions as 8 x 7; a 13 x 23 tile, two of them fit the LDS) where they pad the map less:
         // 27 and 28 pixel maps become 28 x 28 instead of 28 x 32 positions.  Bucket 4 only (a bucket 8 tile would not fit),
@@ -419,14 +419,16 @@ __global__ void dot_params_kernel(const UnitRef* __restrict__ table, int S, int 
 // address of its error column (output channel included), its bilinear factors and the index of the sum it accumulates.  What
 // the lanes of a HALF wave must share is the input channel s: the 4x4x1 MFMA broadcasts its A operand (Xk of a position) per
 // group of 8 blocks with CBSZ = 3 (tools/microbench/mfma_abid checks that), so the two half waves of a wave are independent.
-// So the units of (window, 32 output channels fb, input channel s) -- n_s of them, any number per output channel -- are dealt
-// into H_s = ceil(n_s / 32) HALF-SWEEPS of up to 32 units, round robin in (output channel, unit) order, so that the units of
-// one output channel go to different half-sweeps as far as possible: a half-sweep reads every LDS bank pair at most
-// ceil(count / H_s) times (two units of one output channel in a half-sweep = a two-way bank conflict on their ds_read_b64:
-// LDS cycles the kernel has to spare -- the LDS pipe was 28 % busy --, no wasted lanes).  Round 2 kept lane = output channel
-// (conflict-free reads): an input channel then needs max_f count(s, f) sweeps of 2 x 32 lanes however few of them are used
-// -- 13.0 sweeps per wave and item on BASELINE config 4's uniform offsets against 5.7 here and an ideal of 4.5
-// (tools/slot_histogram.py; the reference splits its large-offset kernels by K instead, dau_conv_backward.cpp:194-231).
+// So the units of (window, 32 output channels fb, input channel s) -- n_s of them, c_f per output channel -- are dealt into
+// H_s = max(ceil(n_s / 32), ceil(max c_f / 2)) HALF-SWEEPS of up to 32 units.  Two units of ONE output channel in a half-sweep
+// read the same LDS bank pair: their ds_read_b64 takes two passes instead of one, for the whole half wave -- and at two passes
+// the LDS pipe, not the matrix pipe, is what the sweep waits for (measured: dealing the units round robin, every half-sweep with
+// some pair of that kind, made a sweep 40 % slower).  So the assignment is greedy per input channel (one thread, counts only):
+// a unit goes where its output channel is not yet present; when it must share, into a half-sweep that already pays for a
+// conflict of that degree.  On BASELINE config 4's uniform offsets that leaves two clean half-sweeps and one with two-way
+// conflicts per input channel: 5.7 sweeps per wave and item against 13.0 in round 2 (lane = output channel, conflict-free: an
+// input channel needed max_f c_f sweeps of 2 x 32 lanes however few were used) and an ideal of 4.5 (tools/slot_histogram.py;
+// the reference splits its large-offset kernels by K instead, dau_conv_backward.cpp:194-231).
 // The half-sweeps of a (window, fb, channel group) are listed in ascending s and dealt out: half-sweep h -> round h / 128, and
 // inside the round wave-half h % 32, entry (h % 128) / 32 -- every wave of every round but the last carries 4 full entries.
 //   params[sub][fb][sg][round][wave][entry][lane][8] = {b00, b01, b10, b11, base, u, soff, 0}
@@ -434,13 +436,20 @@ __global__ void dot_params_kernel(const UnitRef* __restrict__ table, int S, int 
 //   (s*G + g)*F + f, -1 for an empty lane; soff = byte offset of channel s inside its group's Xk planes.
 //   nrounds[(sub*nfb + fb)*nsg + sg] = rounds in use (workgroups of later rounds leave at once).
 // Units whose factors are all zero (ignored units) take no slot.  One workgroup per (window, fb, channel group), 32 channels x
-// 32 output channels at a time.
+// 32 output channels at a time; at most kWlMaxUnits units per channel pair (plans with more fall back to the direct kernels).
+constexpr int kWlMaxUnits = 16;
+
 __global__ void __launch_bounds__(1024) dot_worklist_kernel(const UnitRef* __restrict__ table, int S, int G, int F, int R, int Rt,
                                                             int nsub1, int epitch, int nfb, int nsg, int sgroup, int rounds_max,
                                                             unsigned plane_bytes, float* __restrict__ params,
                                                             int* __restrict__ nrounds, const Guard guard) {
     if (!guard_pass(guard)) return;
     __shared__ int K[32], pre[32], hbase;
+    __shared__ unsigned char cnt[32][32];                       // [channel][output channel]: units in the window
+    __shared__ unsigned short where[32][32][kWlMaxUnits];       // [channel][output channel][k-th unit]: half-sweep << 5 | lane
+    __shared__ unsigned char mult[32][kWlMaxUnits][32];         // [channel][half-sweep][output channel]: units placed
+    __shared__ unsigned char fill[32][kWlMaxUnits], degree[32][kWlMaxUnits];   // lanes used, worst bank-pair multiplicity
+    __shared__ int lane0_base[32][kWlMaxUnits];                                // tile address of the unit in lane 0
     int t = blockIdx.x;
     const int sg = t % nsg; t /= nsg;
     const int fb = t % nfb;
@@ -459,10 +468,14 @@ __global__ void __launch_bounds__(1024) dot_worklist_kernel(const UnitRef* __res
         wy = wy < nsub1 ? wy : nsub1 - 1; wx = wx < nsub1 ? wx : nsub1 - 1;
         return wy == sub / nsub1 && wx == sub % nsub1 && !(u.w00 == 0.0f && u.w01 == 0.0f && u.w10 == 0.0f && u.w11 == 0.0f);
     };
-    auto write_empty = [&](float* dst, unsigned soff) {    // (gathers from its own bank pair at the window centre, zero factors)
+    // an unused lane: zero factors, and the tile address of its half-sweep's lane 0 (identical addresses are broadcast: an address
+    // of its own would put a second address on the bank pair of whichever unit has that output channel); in an entirely
+    // empty half-sweep lane fl reads bank pair fl
+    auto write_empty = [&](float* dst, unsigned soff, int base) {
         dst[0] = 0.0f; dst[1] = 0.0f; dst[2] = 0.0f; dst[3] = 0.0f;
-        dst[4] = __int_as_float(((Rt * epitch + Rt) * kDF + fl) * 8); dst[5] = __int_as_float(-1); dst[6] = __uint_as_float(soff); dst[7] = 0.0f;
+        dst[4] = __int_as_float(base); dst[5] = __int_as_float(-1); dst[6] = __uint_as_float(soff); dst[7] = 0.0f;
     };
+    const int own_base = ((Rt * epitch + Rt) * kDF + fl) * 8;
     if (threadIdx.x == 0) hbase = 0;
     const int s_lo = sg * sgroup, s_hi = s_lo + sgroup < S ? s_lo + sgroup : S;
     for (int s0 = s_lo; s0 < s_hi; s0 += 32) {
@@ -471,45 +484,66 @@ __global__ void __launch_bounds__(1024) dot_worklist_kernel(const UnitRef* __res
         int c = 0;
         if (live)
             for (int g = 0; g < G; ++g) c += in_window(table[((long)s * G + g) * F + f]) ? 1 : 0;
-        // position of this output channel's first unit in the channel's (f, g) order, and the channel's total
-        int incl = c;
-        for (int m = 1; m < 32; m <<= 1) {
-            const int v = __shfl_up(incl, m, 32);
-            if (fl >= m) incl += v;
-        }
-        const int i0 = incl - c, ns = __shfl(incl, 31, 32);
-        const int hs_n = (ns + 31) / 32;                    // half-sweeps of this channel
-        if (fl == 0) K[sl] = s < s_hi ? hs_n : 0;
+        cnt[sl][fl] = (unsigned char)c;
+        int ns = c, cmax = c;                               // units of the channel, most units of one output channel
+        for (int m = 16; m >= 1; m >>= 1) { ns += __shfl_xor(ns, m); cmax = max(cmax, __shfl_xor(cmax, m)); }
+        const int hs_n = max((ns + 31) / 32, (cmax + 1) / 2);   // half-sweeps of this channel
+        if (fl == 0) K[sl] = hs_n;
         __syncthreads();
         if (threadIdx.x == 0) {
             int acc = hbase;
             for (int i = 0; i < 32; ++i) { pre[i] = acc; acc += K[i]; }
             hbase = acc;
         }
+        if (fl == 0 && hs_n > 0) {
+            // greedy placement of the channel's units: cost of a half-sweep = max(its matrix-pipe time, its LDS time), the
+            // LDS time growing with the worst bank-pair multiplicity m (100 : 54 m, the ratio measured for this kernel)
+            auto cost = [](int m) { return m <= 1 ? 100 : 54 * m; };
+            for (int h = 0; h < hs_n; ++h) {
+                fill[sl][h] = 0; degree[sl][h] = 1;
+                for (int j = 0; j < 32; ++j) mult[sl][h][j] = 0;
+            }
+            for (int j = 0; j < 32; ++j)
+                for (int k = 0; k < cnt[sl][j]; ++k) {
+                    int best = 0, best_key = 1 << 30;
+                    for (int h = 0; h < hs_n; ++h) {
+                        if (fill[sl][h] >= 32) continue;
+                        const int m1 = mult[sl][h][j] + 1, d = degree[sl][h];
+                        const int key = (cost(m1 > d ? m1 : d) - cost(d)) * 64 + fill[sl][h];   // cheapest, then emptiest
+                        if (key < best_key) { best_key = key; best = h; }
+                    }
+                    where[sl][j][k] = (unsigned short)(best << 5 | fill[sl][best]);
+                    ++fill[sl][best];
+                    const int m1 = ++mult[sl][best][j];
+                    if (m1 > degree[sl][best]) degree[sl][best] = (unsigned char)m1;
+                }
+        }
         __syncthreads();
         if (s < s_hi && hs_n > 0) {
             const unsigned soff = (unsigned)(s - s_lo) * plane_bytes;
-            int i = i0;
+            int k = 0;
             if (live)
                 for (int g = 0; g < G; ++g) {
                     const UnitRef u = table[((long)s * G + g) * F + f];
                     if (!in_window(u)) continue;
-                    float* dst = slot_ptr(pre[sl] + i % hs_n, i / hs_n);     // unit i -> half-sweep i mod H_s, lane i / H_s
-                    ++i;
+                    const int w_ = where[sl][fl][k++];
+                    float* dst = slot_ptr(pre[sl] + (w_ >> 5), w_ & 31);
                     const int base = (((Rt - (u.oy - cy)) * epitch + (Rt - (u.ox - cx))) * kDF + fl) * 8;
                     dst[0] = u.w00; dst[1] = u.w01; dst[2] = u.w10; dst[3] = u.w11;
                     dst[4] = __int_as_float(base); dst[5] = __int_as_float((int)(((long)s * G + g) * F + f));
                     dst[6] = __uint_as_float(soff); dst[7] = 0.0f;
+                    if ((w_ & 31) == 0) lane0_base[sl][w_ >> 5] = base;
                 }
-            // lanes a half-sweep does not use: half-sweep hs holds the units hs, hs + H_s, ... < n_s
-            for (int hs = 0; hs < hs_n; ++hs)
-                if (fl >= (ns - hs + hs_n - 1) / hs_n) write_empty(slot_ptr(pre[sl] + hs, fl), soff);
         }
+        __syncthreads();
+        if (s < s_hi)
+            for (int h = 0; h < hs_n; ++h)                   // the lanes a half-sweep does not use
+                if (fl >= fill[sl][h]) write_empty(slot_ptr(pre[sl] + h, fl), (unsigned)(s - s_lo) * plane_bytes, lane0_base[sl][h]);
         __syncthreads();
     }
     // the unused half-sweeps of the last round are empty (their lanes gather from channel 0 of the group with zero factors)
     const int total = hbase, rounds = (total + kWlSlots - 1) / kWlSlots;
-    for (int h = total + sl; h < rounds * kWlSlots; h += 32) write_empty(slot_ptr(h, fl), 0u);
+    for (int h = total + sl; h < rounds * kWlSlots; h += 32) write_empty(slot_ptr(h, fl), 0u, own_base);
     if (threadIdx.x == 0) nrounds[blockIdx.x] = rounds;
 }
 
@@ -617,9 +651,12 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     // positions one Xk load covers: 16 (lane 4b+i = kind i of position b of the wave's input channel), or -- window passes --
     // 8 per half wave (lane 32h+4b+i = kind i of position b of half h's input channel): one region row
     constexpr int kPPS = BINNED ? 8 : 16;
-    constexpr int kXSlots = BINNED ? RH : (RW == 8 ? (RH + 1) / 2 : (RH * RW + 15) / 16);
+    // ring depth: window passes keep four region rows of Xk in flight (half a sweep of an 8-row region; a ring of eight would cost
+    // sixteen registers the kernel does not have); row r of a sweep lives in slot r % 4
+    constexpr int kXSlots = BINNED ? (RH < 4 ? RH : 4) : (RW == 8 ? (RH + 1) / 2 : (RH * RW + 15) / 16);
     constexpr int kCBSZ = BINNED ? 3 : 4;            // A operand broadcast over all 16 blocks, or within each half wave
     static_assert(RW == 8 || (RW % 2 == 0 && !BINNED), "region width");
+    static_assert(!BINNED || RH % 4 == 0, "window passes: row r of a sweep lives in ring slot r % 4");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (!guard_pass(a.guard)) return;
     const int lane = threadIdx.x & 63;
@@ -655,7 +692,6 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     // per-lane parameters of the wave's AS x GP units, resident in registers for the whole kernel
     f2 bw[AS][GP][2];
     unsigned base[AS][GP];      // RING: (the lane's first tile row) << 16 | byte offset inside a row
-    int gidx[AS][GP];           // BINNED: the lane's flat unit index (s*G + g)*F + f, -1 for an empty lane
     unsigned xv[AS];            // BINNED: the lane's Xk offset: its half wave's input channel plane + (lane & 31) * 8
     int s_of[AS];
     bool act[AS];               // BINNED: some lane of the wave has a unit in entry si (wave-uniform)
@@ -678,14 +714,13 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                 const unsigned br = base[si][gp] / rb;
                 base[si][gp] = (br << 16) | (base[si][gp] - br * rb);       // a row is at most 27 positions x 256 B
             }
-            gidx[si][gp] = BINNED ? __float_as_int(p[5]) : 0;
-            if constexpr (BINNED) xv[si] = __float_as_uint(p[6]) + (unsigned)(lane & 31) * 8u;
+            if constexpr (BINNED) {
+                act[si] = __ballot(__float_as_int(p[5]) >= 0) != 0ull;   // (the unit index itself is re-read at flush time)
+                xv[si] = __float_as_uint(p[6]) + (unsigned)(lane & 31) * 8u;
+            }
         }
         if constexpr (BINNED) {
-            bool any = false;
-#pragma unroll
-            for (int gp = 0; gp < GP; ++gp) any = any || gidx[si][gp] >= 0;
-            act[si] = __ballot(any) != 0ull;
+            // (act[si] was set with the parameters above)
         }
     }
     int first_act = 0;          // first input channel of the wave that has units; AS: none
@@ -818,9 +853,12 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     }
     // The fp32 accumulators leave for the (double) partial sums every kFlushItems items: ~1024 products per chain.
     // partial[chunk][k][(s*G+g)*F+f] += image 0 + image 1.  Every unit is written by exactly one workgroup per chunk: its own
-    // (unit block) pass, or -- BINNED -- the pass of the one (window, slot) it was binned into; so this is a plain
-    // read-modify-write in a fixed order (deterministic, no atomics).  The first flush stores.
-    constexpr int kFlushTerms = 512;
+    // (unit block) pass, or -- BINNED -- the pass of the one (window, half-sweep) it was dealt into; so these are additions by
+    // ONE lane in program order (deterministic).  The first flush stores.
+#ifndef DAU_DOT_FLUSH_TERMS
+#define DAU_DOT_FLUSH_TERMS 1024
+#endif
+    constexpr int kFlushTerms = DAU_DOT_FLUSH_TERMS;
     constexpr int kFlushItems = kFlushTerms / (RH * RW) > 0 ? kFlushTerms / (RH * RW) : 1;
     const long units = (long)a.S * a.G * a.F;
     bool flushed = false;
@@ -833,14 +871,20 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                 const int s = s_of[si], g = a.g_begin + gb * 2 * GP + 2 * gp + half;
                 // one entry at a time, its address computed here and now: the kernel has no registers to spare for sixteen
                 // loads in flight or for addresses hoisted out of the item loop (the empty asm pins the computation here)
-                int u = BINNED ? gidx[si][gp] : (s * a.G + g) * a.F + f;
+                int u = (s * a.G + g) * a.F + f;
+                if constexpr (BINNED)
+                    u = __float_as_int(a.params[(((((((long)sub * a.nfb + fb) * a.nsb + sb) * a.ngb + gb) * kDWaves + wave) * AS + si) * 64 + lane) * kParamDwords + 5]);
                 asm volatile("" : "+v"(u));
                 if (BINNED ? u >= 0 : (s < a.S && g < a.G && f < a.F)) {
                     double* dst = a.partial + (long)chunk * kNumK * units + u;
 #pragma unroll
                     for (int kk = 0; kk < kNumK; ++kk) {
                         const double v = (double)acc[si][gp][0][kk] + (double)acc[si][gp][1][kk];
-                        dst[kk * units] = flushed ? dst[kk * units] + v : v;
+                        // the first flush stores; the later ones add with the hardware's fp64 atomic (no return value: nothing to
+                        // wait for -- a load / add / store round trip per entry cost 0.8 ms of the 17 ms north-star pass).
+                        // The slot belongs to this lane alone, so the order of the additions is the program's.
+                        if (flushed) unsafeAtomicAdd(&dst[kk * units], v);
+                        else dst[kk * units] = v;
                     }
                 }
                 acc[si][gp][0] = f4{0, 0, 0, 0}; acc[si][gp][1] = f4{0, 0, 0, 0};
@@ -865,6 +909,45 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
         // flight, after that the tile has had a whole sweep of time and the waits cover it.
         if (two) issue_next(item + 1 < item1 && !(a.debug & 2) ? item + 1 : item, buf ^ 1);
         const unsigned bufoff = buf * tile_bytes;
+        // positions per group: with one unit pair per wave four positions give the same 16 packed + 8 MFMA run as two
+        // positions with two pairs (pipe switches are expensive, tools/microbench/mfma_pk_grouping)
+        constexpr int GS = GP == 1 ? 4 : 2;
+        f2 eb[2][GP][2][GS];         // [buffer parity][unit pair][row: 0 = tile row j (dy=1), 1 = row j+1 (dy=0)][col]
+        f2 epn[GP][2];               // column 0 of a row (precedes its first group)
+        unsigned rowaddr[GP], rowaddr2[GP];
+        int slot2[GP];               // RING: ring slot of rowaddr2's tile row
+        unsigned bcol[GP];           // RING: the lane's byte offset inside a tile row
+        // address of the tile row below rowaddr2's
+        auto row_below = [&](int gp) -> unsigned {
+            if constexpr (RING) return slot2[gp] + 1 == a.erows ? bcol[gp] : rowaddr2[gp] + row_bytes;
+            else return rowaddr2[gp] + row_bytes;
+        };
+        // tile rows 0 and 1 of the sweep of the entry whose (packed) base is b
+        auto rows_for = [&](unsigned b, int gp) {
+            if constexpr (RING) {
+                bcol[gp] = b & 0xffffu;
+                int sl = origin + (int)(b >> 16);
+                sl = sl >= a.erows ? sl - a.erows : sl;
+                rowaddr[gp] = (unsigned)sl * row_bytes + bcol[gp];
+                slot2[gp] = sl + 1 == a.erows ? 0 : sl + 1;
+                rowaddr2[gp] = (unsigned)slot2[gp] * row_bytes + bcol[gp];
+            } else {
+                rowaddr[gp] = b + bufoff;
+                rowaddr2[gp] = rowaddr[gp] + row_bytes;
+            }
+        };
+        // column `col` of a sweep's first group (and, with col 0, the column that precedes it) into buffer 0
+        auto prime_col = [&](int col) {
+#pragma unroll
+            for (int gp = 0; gp < GP; ++gp) {
+                if (col == 0) {
+                    lds_read(epn[gp][0], rowaddr[gp], 0);
+                    lds_read(epn[gp][1], rowaddr2[gp], 0);
+                }
+                lds_read(eb[0][gp][0][col], rowaddr[gp], (1 + col) * (kDF * 8));
+                lds_read(eb[0][gp][1][col], rowaddr2[gp], (1 + col) * (kDF * 8));
+            }
+        };
 #pragma unroll
         for (int si = 0; si < AS; ++si) {
             if (BINNED && !act[si]) continue;     // wave-uniform: no unit of this input channel in the wave's slots
@@ -883,43 +966,15 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                                              : nxt < AS ? sweep_ptr(item, s_base + nxt)
                                                         : (item + 1 < item1 ? sweep_ptr(item + 1, s_base + first_act) : xbase);
 
-            // The sweep over the 8x8 region is fully unrolled (no back-edge copies).  Software pipeline over groups
-            // of two positions: at the END of a group one lgkmcnt(0) retires the error columns prefetched for the
-            // next group, which flew under this group's work.
-            // positions per group: with one unit pair per wave four positions give the same 16 packed + 8 MFMA run as two
-            // positions with two pairs (pipe switches are expensive, tools/microbench/mfma_pk_grouping)
-            constexpr int GS = GP == 1 ? 4 : 2;
-            f2 eb[2][GP][2][GS];         // [buffer parity][unit pair][row: 0 = tile row j (dy=1), 1 = row j+1 (dy=0)][col]
-            f2 epn[GP][2];               // column 0 of a row (precedes its first group)
-            unsigned rowaddr[GP], rowaddr2[GP];
-            int slot2[GP];               // RING: ring slot of rowaddr2's tile row
-            // address of the tile row below rowaddr2's
-            unsigned bcol[GP];           // RING: the lane's byte offset inside a tile row
-            auto row_below = [&](int gp) -> unsigned {
-                if constexpr (RING) return slot2[gp] + 1 == a.erows ? bcol[gp] : rowaddr2[gp] + row_bytes;
-                else return rowaddr2[gp] + row_bytes;
-            };
+            // The sweep over the region is fully unrolled (no back-edge copies).  Software pipeline over groups of GS positions:
+            // at the END of a group one lgkmcnt(0) retires the error columns prefetched for the next group, which flew under
+            // this group's work.  (Tried in round 3: the last group of a sweep requesting the first group of the item's next
+            // sweep, so that only the first sweep of an item starts with an exposed LDS round trip -- no gain at the north-star
+            // shape, 18.05 vs 18.12 ms, and 3 % slower in the window passes, which have no registers for it.)
 #pragma unroll
-            for (int gp = 0; gp < GP; ++gp) {
-                if constexpr (RING) {
-                    bcol[gp] = base[si][gp] & 0xffffu;
-                    int sl = origin + (int)(base[si][gp] >> 16);
-                    sl = sl >= a.erows ? sl - a.erows : sl;
-                    rowaddr[gp] = (unsigned)sl * row_bytes + bcol[gp];
-                    slot2[gp] = sl + 1 == a.erows ? 0 : sl + 1;
-                    rowaddr2[gp] = (unsigned)slot2[gp] * row_bytes + bcol[gp];
-                } else {
-                    rowaddr[gp] = base[si][gp] + bufoff;
-                    rowaddr2[gp] = rowaddr[gp] + row_bytes;
-                }
-                lds_read(epn[gp][0], rowaddr[gp], 0);
-                lds_read(epn[gp][1], rowaddr2[gp], 0);
+            for (int gp = 0; gp < GP; ++gp) rows_for(base[si][gp], gp);
 #pragma unroll
-                for (int cc = 0; cc < GS; ++cc) {
-                    lds_read(eb[0][gp][0][cc], rowaddr[gp], (1 + cc) * (kDF * 8));
-                    lds_read(eb[0][gp][1][cc], rowaddr2[gp], (1 + cc) * (kDF * 8));
-                }
-            }
+            for (int cc = 0; cc < GS; ++cc) prime_col(cc);
             lgkm_wait0();
 #pragma unroll
             for (int j = 0; j < kRH; ++j) {
@@ -1022,7 +1077,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                     for (int p = 0; p < GS; ++p) {
 #pragma unroll
                         for (int gp = 0; gp < GP; ++gp) {
-                            const int abid = (pos0 + p) % kPPS, slot = (pos0 + p) / kPPS;     // position within the slot's 16 (8)
+                            const int abid = (pos0 + p) % kPPS, slot = ((pos0 + p) / kPPS) % kXSlots;     // position within the slot's 16 (8)
                             acc[si][gp][0] = mfma_bcast<kCBSZ>(xr[slot].x, et[p][gp].x, acc[si][gp][0], abid);
                             acc[si][gp][1] = mfma_bcast<kCBSZ>(xr[slot].y, et[p][gp].y, acc[si][gp][1], abid);
                         }
@@ -1032,7 +1087,12 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                     // the slot is consumed: refill it with the same positions of the next sweep
-                    if ((pos0 + GS) % kPPS == 0 || pos0 + GS == kRH * kRW) x_fetch(xr[pos0 / kPPS], xnext_sweep, pos0 / kPPS, vnext);
+                    if ((pos0 + GS) % kPPS == 0 || pos0 + GS == kRH * kRW) {
+                        constexpr int kLoads = BINNED ? RH : kXSlots;        // loads per sweep
+                        const int ld = pos0 / kPPS + kXSlots;                // the load that takes the freed slot
+                        if (ld < kLoads) x_fetch(xr[(pos0 / kPPS) % kXSlots], xbase, ld, BINNED ? xv[si] : 0u);
+                        else x_fetch(xr[(pos0 / kPPS) % kXSlots], xnext_sweep, ld - kLoads, vnext);
+                    }
                     lgkm_wait0();   // the prefetched group has landed
                 }
                 // next row: tile rows shift down by one
@@ -1119,7 +1179,12 @@ void dispatch_dot(bool binned, bool ring, int RW, int RH, int GP, int AS, hipStr
     }
     if (binned) {
         // window passes: the tile is a ring of rows (DAU_DOT_RING=0 at plan creation: whole tiles, for A/B)
-        if (ring) launch_dot<1, 4, 4, true, 8, true>(st, a, grid, lds);
+        if (ring) {
+            if (RH == 8) launch_dot<1, 4, 8, true, 8, true>(st, a, grid, lds);
+            else launch_dot<1, 4, 4, true, 8, true>(st, a, grid, lds);
+            return;
+        }
+        if (RH == 8) launch_dot<1, 4, 8, true>(st, a, grid, lds);
         else launch_dot<1, 4, 4, true>(st, a, grid, lds);
     } else if (RH == 8) {
         if (GP == 1) launch_dot<1, 4, 8>(st, a, grid, lds);
@@ -1175,6 +1240,7 @@ bool tiled_dot_configure(const Shape& sh, int R, int blur_k, bool bf16, int igno
     const DotGeometry g = make_dot_geometry(sh, R, as1, one_tile, rounds, rw8);
     if (g.nbuf * g.tile_bytes > 160 * 1024) return false;
     if (g.nsub1 > 1 && g.sgroup == 0) return false;          // one Xk plane of 2 GiB and more: maps beyond ~1400 x 1400
+    if (g.nsub1 > 1 && sh.G > kWlMaxUnits) return false;     // the work list places at most 16 units per channel pair
     // immediates of the unrolled column walk must fit 16 bits
     if ((size_t)g.epitch * kDF * 8 + (g.RW + 1) * kDF * 8 > 65535) return false;
     {
