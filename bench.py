@@ -154,13 +154,13 @@ def lib_fingerprint():
 
 def measured_traffic(workload_key, io, dominant):
     """HBM bytes per pass of the dominant kernel from the committed rocprofv3 --pmc passes of THIS command
-    (tools/pmc_traffic.sh writes profiles/r2_pmc_traffic.json: counters cannot be read from inside the process).  Only
+    (tools/pmc_traffic.sh writes profiles/r3_pmc_traffic.json: counters cannot be read from inside the process).  Only
     used when that file was taken for this workload with this very build of the library; otherwise null + the reason."""
-    path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
     try:
         pmc = json.load(open(path))
     except Exception:
-        return None, "no PMC pass committed for this build (profiles/r2_pmc_traffic.json missing)"
+        return None, "no PMC pass committed for this build (profiles/r3_pmc_traffic.json missing)"
     run = pmc.get("runs", {}).get("%s/%s" % (workload_key, io))
     if run is None:
         return None, "no PMC pass committed for workload %s/%s" % (workload_key, io)
@@ -171,7 +171,7 @@ def measured_traffic(workload_key, io, dominant):
     fam = run["kernels"].get(key)       # the family entry: all instantiations / window launches of one pass
     if not fam or "hbm_bytes_per_pass" not in fam:
         return None, "dominant kernel not in the committed PMC pass"
-    return round(fam["hbm_bytes_per_pass"] / 1e9, 3), "profiles/r2_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, separate passes)"
+    return round(fam["hbm_bytes_per_pass"] / 1e9, 3), "profiles/r3_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, separate passes)"
 
 
 def main():

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic per kernel from PMC counters: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), no trace
 # domains, as /opt/skills/guides/MI355X_MICROARCH.md prescribes.  Writes gpurun_out/<tag>_pmc_traffic.json in the format
-# bench.py reads from profiles/r2_pmc_traffic.json (merge the "runs" entries there and commit).
+# bench.py reads from profiles/r3_pmc_traffic.json (merge the "runs" entries there and commit).
 # usage (on the GPU box, from the repo root): tools/pmc_traffic.sh <tag> <workload> <io> [more bench args...]
 TAG=$1; WL=$2; IO=$3; shift 3
 STEPS=3; WARM=1
