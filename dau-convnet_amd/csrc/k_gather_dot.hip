@@ -580,7 +580,7 @@ struct DotArgs {
     int Rt, nsub1;
     int rx, ry, EX, EY, Hp, Wp, epitch, erows, s_pad;
     unsigned tile_bytes;
-    int debug;   // timing experiments only (DAU_DOT_DEBUG): 1 = Xk always from one address, 2 = no error-tile refills
+    int debug;   // timing experiments only (tuning build, DAU_DOT_DEBUG): 1 = Xk always of the chunk's first item, 2 = no error-tile refills
     Guard guard;
 };
 
@@ -828,6 +828,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
         else x_load(dst, xoff[t], base, 0);
     };
     auto sweep_ptr = [&](int item, int s) -> const char* {
+        if (a.debug & 1) item = item0;      // timing experiment (tuning build): every item reads the Xk of the chunk's first one
         const int np_ = item / regions, reg_ = item % regions;
         const int ry_ = RING ? reg_ % a.ry : reg_ / a.rx, rx_ = RING ? reg_ / a.ry : reg_ % a.rx;
         return reinterpret_cast<const char*>(a.xk) +
