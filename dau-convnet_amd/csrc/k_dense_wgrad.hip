@@ -170,7 +170,13 @@ struct WgGemmArgs {
 // which drains everything for its barrier anyway.  NSTEP = columns of a row = the instantiation (window slot = column mod 10
 // and E' slot = column mod 6 are then compile-time constants for any row length).
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-#define WG_ELOAD(dst, voff, sbase) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory")
+// (the base goes through an s_mov_b64 inside the block: an SGPR that the register allocator reloads by v_readlane_b32 right before
+// the block must not be read by a vector memory instruction within 5 cycles -- see x_load in k_gather_dot.hip)
+#define WG_ELOAD(dst, voff, sbase)                                                                                         \
+    do {                                                                                                                   \
+        unsigned long long sb_;                                                                                            \
+        asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx4 %0, %2, %1" : "=v"(dst), "=&s"(sb_) : "v"(voff), "s"(sbase) : "memory"); \
+    } while (0)
 template <int N>
 __device__ __forceinline__ void wg_vmwait() {
     __builtin_amdgcn_sched_barrier(0);

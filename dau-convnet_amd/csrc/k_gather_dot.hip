@@ -56,6 +56,9 @@ constexpr int kRW = 8;           // region of positions q handled per item: kRW 
 #define DAU_DOT_WAVES 16
 #endif
 constexpr int kDWaves = DAU_DOT_WAVES;
+#ifndef DAU_DOT_STRIDE
+#define DAU_DOT_STRIDE 1
+#endif
 #ifndef DAU_DOT_PRIO
 #define DAU_DOT_PRIO 0          // timing experiment: 1 = s_setprio 2 around the MFMA burst, 2 = 1 / 3 / 0 for interpolation / MFMA / reads
 #endif
@@ -76,6 +79,7 @@ struct DotGeometry {
     // Several offset windows (R > 8, "binned"): one pass over the WORK LIST of every (window, fb, channel group)
     // (dot_worklist_kernel): AS = 4 entries per wave and round, ngb = rounds allocated, nsb = channel groups.
     struct Pass { int g_begin, GP, AS, ngb, sblock, nsb, chunks; size_t params_off, params_bytes; };
+    int rounds_launched;        // binned: workgroups per work list in the grid (a workgroup strides over the list's rounds)
     int sgroup;                 // binned: input channels per channel group (their Xk planes span less than 2 GiB, so that a
                                 // lane's channel offset fits the 32-bit VGPR offset of a global load); 0: shape not supported
     int npass;
@@ -168,14 +172,19 @@ DotGeometry make_dot_geometry(const Shape& sh, int R, bool as1 = false, bool one
     for (int i = 0; i < g.npass; ++i) {
         // at most four full rounds of 256 workgroups (one more workgroup would add a whole, nearly empty round), no
         // more chunks than items, and no chunk without items
-        // binned: the rounds a work list really uses depend on the offsets (the others leave at once); the grid is sized for
-        // the evenly spread case -- an input channel needs its mean number of units per (window, output channel), rounded up, as
-        // half-sweeps -- and for 32 busy workgroups per CU, so that the tail of the last workgroups stays short
+        // binned: how many rounds a work list uses depends on the offsets and is known on the device only.  The grid holds ONE
+        // workgroup per (chunk, work list), which walks the list's rounds one after the other: no workgroup without work
+        // unless a window is empty.  That matters more than it seems: workgroups that leave at once MIXED with ones that
+        // run for milliseconds cost C4 14 % (same box: 794 ms with 7 workgroups per list where every list has 6 rounds,
+        // 681 ms with 6, 685 ms with 3 -- each taking two rounds --, 803 ms with 20) although a grid of nothing but such
+        // workgroups passes in 35 us: blocks go to the XCDs round robin and in order, so XCDs that draw the idle ones run
+        // ahead and then wait for the dispatcher, which is held up by a block bound for an XCD that is still full.
+        // Chunks for 32 workgroups per CU, so that the tail stays short.
         int per_chunk = g.nfb * g.pass[i].nsb * g.pass[i].ngb;
         if (binned) {
-            const double per_s = (double)sh.G / (g.nsub1 * g.nsub1) + 1.0;   // half-sweeps of 32 units per input channel
-            const int est = (int)((g.sgroup ? g.sgroup : 32) * (per_s < sh.G ? per_s : sh.G) / kWlSlots) + 1;
-            per_chunk = g.nfb * g.pass[i].nsb * g.nsub1 * g.nsub1 * est;
+            const int want = DAU_TUNE_INT("DAU_DOT_RLAUNCH", 1);
+            g.rounds_launched = want < g.pass[i].ngb ? (want > 1 ? want : 1) : g.pass[i].ngb;
+            per_chunk = g.nfb * g.pass[i].nsb * g.nsub1 * g.nsub1 * g.rounds_launched;
         }
         // rounds: workgroups per CU the grid is sized for.  More chunks = a finer tail, at 32 B of partial sums (double) per
         // unit and chunk; at the north-star shape 4, 8 and 16 rounds take the same time (same-box A/B,
@@ -577,6 +586,7 @@ struct DotArgs {
     int NP, nfb, nsb, ngb, nbuf, chunks, items;   // window passes (work list): nsb = channel groups, ngb = rounds allocated
     const int* nrounds;         // window passes: rounds in use per (window, fb, channel group)
     int sgroup;                 // window passes: input channels per channel group
+    int rmax;                   // window passes: rounds allocated per work list (ngb of them are launched; a workgroup strides)
     int Rt, nsub1;
     int rx, ry, EX, EY, Hp, Wp, epitch, erows, s_pad;
     unsigned tile_bytes;
@@ -597,7 +607,17 @@ __device__ __forceinline__ f2 pk_fma_s(f2 a, f2 s, f2 c) { return __builtin_elem
 #define lds_read(dst, addr, imm) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
 #define lds_read_imm(dst, addr, imm) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(imm) : "memory")
 // Xk ring: the destination is a read-write operand so that the register stays put across loop back-edges.
-#define x_load(dst, voff, sbase, imm) asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "+v"(dst) : "v"(voff), "s"(sbase), "n"(imm) : "memory")
+// The base first goes through an s_mov_b64 inside the asm block: when the register allocator has to spill SGPRs (this kernel sits
+// at the limit), the base arrives by v_readlane_b32 -- a VALU write of an SGPR -- and a vector memory instruction that reads such
+// an SGPR within 5 cycles reads the OLD value (the manual-hazard table of the ISA; hipcc's hazard recognizer does not look into
+// asm blocks).  Seen as a memory fault at "null + offset" when a loop around the kernel body raised the SGPR pressure.  A scalar
+// instruction reading the SGPR is interlocked, and scalar-write -> vector-memory-read needs no wait states.
+#define x_load(dst, voff, sbase, imm)                                                                                      \
+    do {                                                                                                                   \
+        unsigned long long sb_;                                                                                            \
+        asm volatile("s_mov_b64 %1, %3\n\tglobal_load_dwordx2 %0, %2, %1 offset:%4"                                         \
+                     : "+v"(dst), "=&s"(sb_) : "v"(voff), "s"(sbase), "n"(imm) : "memory");                                \
+    } while (0)
 // ring of kXSlots loads: the oldest is complete when at most kXSlots - 1 (+ tile loads in between) are outstanding
 template <int N>
 __device__ __forceinline__ void x_wait() {
@@ -672,7 +692,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
         logical = (xcd < rem ? xcd * (chunk_ + 1) : rem * (chunk_ + 1) + (xcd - rem) * chunk_) + idx;
     }
     const int sb = logical % a.nsb;                  // block of input channels (window passes: channel group)
-    const int gb = (logical / a.nsb) % a.ngb;        // block of units (window passes: round of the work list)
+    int gb = (logical / a.nsb) % a.ngb;              // block of units (window passes: first round of the work list)
     const int fb = (logical / (a.nsb * a.ngb)) % a.nfb;
     const int nsub = a.nsub1 * a.nsub1;
     const int sub = (logical / (a.nsb * a.ngb * a.nfb)) % nsub;
@@ -680,14 +700,21 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     // tile origin of this pass's offset window inside the staged error plane (0 when one tile covers the bucket)
     const int sub_dy = 2 * (a.R - a.Rt) - 2 * a.Rt * (sub / a.nsub1), sub_dx = 2 * (a.R - a.Rt) - 2 * a.Rt * (sub % a.nsub1);
 
+    // Window passes: the grid holds a.ngb (= 1 unless a tuning knob says otherwise) workgroups per (chunk, window, fb, channel
+    // group), and workgroup gb takes the rounds gb, gb + a.ngb, ... of the work list, however many there are (a.rmax are
+    // allocated): see make_dot_geometry for why the grid is not sized for the worst case.
+    int nr = 1;
     if constexpr (BINNED) {
-        // rounds beyond the ones the work list of this (window, fb, channel group) uses: nothing to do
-        if (gb >= a.nrounds[(sub * a.nfb + fb) * a.nsb + sb]) return;
+        nr = a.nrounds[(sub * a.nfb + fb) * a.nsb + sb];
+        if (gb >= nr) return;
     }
     // this chunk's contiguous range of items (image pair, region)
     const int per = (a.items + a.chunks - 1) / a.chunks;
     const int item0 = chunk * per;
     const int item1 = item0 + per < a.items ? item0 + per : a.items;
+#if DAU_DOT_STRIDE
+    for (;;) {
+#endif
 
     // per-lane parameters of the wave's AS x GP units, resident in registers for the whole kernel
     f2 bw[AS][GP][2];
@@ -703,7 +730,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
         act[si] = true;
 #pragma unroll
         for (int gp = 0; gp < GP; ++gp) {
-            const float* p = BINNED ? a.params + (((((((long)sub * a.nfb + fb) * a.nsb + sb) * a.ngb + gb) * kDWaves + wave) * AS + si) * 64 + lane) * kParamDwords
+            const float* p = BINNED ? a.params + (((((((long)sub * a.nfb + fb) * a.nsb + sb) * a.rmax + gb) * kDWaves + wave) * AS + si) * 64 + lane) * kParamDwords
                                     : a.params + ((((((long)sub * a.s_pad + s) * a.ngb + gb) * GP + gp) * a.nfb + fb) * 64 + lane) * kParamDwords;
             bw[si][gp][0] = f2{p[0], p[1]};
             bw[si][gp][1] = f2{p[2], p[3]};
@@ -874,7 +901,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                 // loads in flight or for addresses hoisted out of the item loop (the empty asm pins the computation here)
                 int u = (s * a.G + g) * a.F + f;
                 if constexpr (BINNED)
-                    u = __float_as_int(a.params[(((((((long)sub * a.nfb + fb) * a.nsb + sb) * a.ngb + gb) * kDWaves + wave) * AS + si) * 64 + lane) * kParamDwords + 5]);
+                    u = __float_as_int(a.params[(((((((long)sub * a.nfb + fb) * a.nsb + sb) * a.rmax + gb) * kDWaves + wave) * AS + si) * 64 + lane) * kParamDwords + 5]);
                 asm volatile("" : "+v"(u));
                 if (BINNED ? u >= 0 : (s < a.S && g < a.G && f < a.F)) {
                     double* dst = a.partial + (long)chunk * kNumK * units + u;
@@ -1126,6 +1153,15 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     flush();
+#if DAU_DOT_STRIDE
+    if constexpr (!BINNED) break;
+    else {
+        gb += a.ngb;                // the next round of this workgroup's stride
+        if (gb >= nr) break;
+        __syncthreads();            // every wave is done with the tile before the next round refills it
+    }
+    }
+#endif
 }
 
 
@@ -1325,8 +1361,9 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
     for (int i = 0; i < g.npass; ++i) {           // every pass writes its own units' slabs of the partial sums
         const DotGeometry::Pass& ps = g.pass[i];
         a.params = reinterpret_cast<const float*>(ws + l.params_off + ps.params_off);
-        a.g_begin = ps.g_begin; a.nsb = ps.nsb; a.ngb = ps.ngb; a.chunks = ps.chunks;
-        const int grid = ps.chunks * g.nsub1 * g.nsub1 * g.nfb * ps.ngb * ps.nsb;
+        a.g_begin = ps.g_begin; a.nsb = ps.nsb; a.chunks = ps.chunks;
+        a.rmax = ps.ngb; a.ngb = binned ? g.rounds_launched : ps.ngb;
+        const int grid = ps.chunks * g.nsub1 * g.nsub1 * g.nfb * a.ngb * ps.nsb;
         dispatch_dot(binned, c.ring, g.RW, g.RH, ps.GP, ps.AS, st, &a, grid, lds);
     }
     const long n = (long)kNumK * s.S * s.G * s.F;

@@ -12,6 +12,6 @@ while read -r secs tag cmd; do
   rc=$?
   echo "=== $tag rc=$rc ($(( $(date +%s) - start )) s)"
   tail -n 6 "gpurun_out/$tag.log" | cut -c1-600
-  if [ $rc -ge 124 ]; then echo "step $tag was killed (rc=$rc): stopping"; exit $rc; fi
+  if [ $rc -ge 124 ] && [ $rc -ne 134 ]; then echo "step $tag was killed (rc=$rc): stopping"; exit $rc; fi
 done
 exit 0
