@@ -104,6 +104,8 @@ const Variant kVariants[] = {
                                         //     28x28 at 512 channels: 11.0 / 11.6 -> 10.5 / 10.9 ms).  Sixteen channels = 1024
                                         //     threads spill (20x slower): not instantiated.
     {4, 4, 104, 0, 1, 1, 0, 12, 0},     // 22: 31 pixel patches, R <= 28, twelve channels (512x512, bucket 18: 250 -> 242 ms per pass)
+    {4, 4, 72, 0, 1, 1, 0, 12, 0},      // 23: 31 pixel patches, R <= 20, twelve channels on a pitch-72 plane: a third fewer staged
+                                        //     bytes to write, fetch and hold than row 22 for the buckets that fit (16, 18, 20)
 };
 
 // one (channel block, input channel) slice of the packed unit table: [G slots][fb channels][8 dwords]; window passes
@@ -795,6 +797,7 @@ void dispatch_variant(int variant, hipStream_t st, const GatherArgs* a, int grid
         case 20: launch_variant<GatherTraits<7, 7, 72, true, 2, 1, 0, 4, 3>>(st, a, grid, lds); break;
         case 21: launch_variant<GatherTraits<4, 4, 40, false, 1, 1, 0, 12>>(st, a, grid, lds); break;
         case 22: launch_variant<GatherTraits<4, 4, 104, false, 1, 1, 0, 12>>(st, a, grid, lds); break;
+        case 23: launch_variant<GatherTraits<4, 4, 72, false, 1, 1, 0, 12>>(st, a, grid, lds); break;
         default: break;
     }
 }
