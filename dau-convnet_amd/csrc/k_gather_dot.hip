@@ -743,7 +743,8 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
             }
             if constexpr (BINNED) {
                 act[si] = __ballot(__float_as_int(p[5]) >= 0) != 0ull;   // (the unit index itself is re-read at flush time)
-                xv[si] = __float_as_uint(p[6]) + (unsigned)(lane & 31) * 8u;
+                // slot layout of the window passes: lane 32 h + 4 b + i = kind i of position (row b % 4, column b / 4) of half h's channel
+                xv[si] = __float_as_uint(p[6]) + (unsigned)((lane >> 2) & 3) * (unsigned)(a.Wp * 32) + (unsigned)((lane >> 4) & 1) * 32u + (unsigned)(lane & 3) * 8u;
             }
         }
         if constexpr (BINNED) {
@@ -850,7 +851,7 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     // slot t of the sweep that starts at `base`
     // (window passes: `base` is the sweep origin in the channel group's first plane, voff the lane's channel + position offset)
     auto x_fetch = [&](f2& dst, const char* base, int t, unsigned voff) {
-        if constexpr (BINNED) x_load(dst, voff, base + t * xpitch, 0);
+        if constexpr (BINNED) x_load(dst, voff, base + (size_t)(t / 4) * 4 * xpitch + (t % 4) * 64, 0);   // column pair t % 4 of row block t / 4
         else if constexpr (RW == 8) x_load(dst, xlane, base + 2 * t * xpitch, 0);
         else x_load(dst, xoff[t], base, 0);
     };
@@ -976,6 +977,27 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                 lds_read(eb[0][gp][1][col], rowaddr2[gp], (1 + col) * (kDF * 8));
             }
         };
+#define DAU_INTERP4(o0, o1, o2, o3, E0, L0, E1, L1, A0, A1, A2, A3, B0, B1, B2, B3)                                  \
+    asm volatile("v_pk_mul_f32 %0, %4, %20 op_sel_hi:[1,0]\n\t"                                                     \
+                 "v_pk_mul_f32 %1, %5, %21 op_sel_hi:[1,0]\n\t"                                                     \
+                 "v_pk_mul_f32 %2, %6, %22 op_sel_hi:[1,0]\n\t"                                                     \
+                 "v_pk_mul_f32 %3, %7, %23 op_sel_hi:[1,0]\n\t"                                                     \
+                 "v_pk_fma_f32 %0, %8, %20, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                                \
+                 "v_pk_fma_f32 %1, %9, %21, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                                \
+                 "v_pk_fma_f32 %2, %10, %22, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                               \
+                 "v_pk_fma_f32 %3, %11, %23, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                               \
+                 "v_pk_fma_f32 %0, %12, %24, %0 op_sel_hi:[1,0,1]\n\t"                                              \
+                 "v_pk_fma_f32 %1, %13, %25, %1 op_sel_hi:[1,0,1]\n\t"                                              \
+                 "v_pk_fma_f32 %2, %14, %26, %2 op_sel_hi:[1,0,1]\n\t"                                              \
+                 "v_pk_fma_f32 %3, %15, %27, %3 op_sel_hi:[1,0,1]\n\t"                                              \
+                 "v_pk_fma_f32 %0, %16, %24, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                               \
+                 "v_pk_fma_f32 %1, %17, %25, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                               \
+                 "v_pk_fma_f32 %2, %18, %26, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                               \
+                 "v_pk_fma_f32 %3, %19, %27, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]"                                    \
+                 : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)                                                         \
+                 : "v"(E0[0]), "v"(E0[1]), "v"(E0[2]), "v"(E0[3]), "v"(L0[0]), "v"(L0[1]), "v"(L0[2]), "v"(L0[3]),   \
+                   "v"(E1[0]), "v"(E1[1]), "v"(E1[2]), "v"(E1[3]), "v"(L1[0]), "v"(L1[1]), "v"(L1[2]), "v"(L1[3]),   \
+                   "v"(A0), "v"(A1), "v"(A2), "v"(A3), "v"(B0), "v"(B1), "v"(B2), "v"(B3))
 #pragma unroll
         for (int si = 0; si < AS; ++si) {
             if (BINNED && !act[si]) continue;     // wave-uniform: no unit of this input channel in the wave's slots
@@ -994,6 +1016,78 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                                              : nxt < AS ? sweep_ptr(item, s_base + nxt)
                                                         : (item + 1 < item1 ? sweep_ptr(item + 1, s_base + first_act) : xbase);
 
+            if constexpr (BINNED) {
+                // ---- window passes: the sweep in COLUMN groups ---------------------------------------------------------------
+                // A group is the four region rows of ONE column: its positions need the error at tile rows r .. r+4 of columns
+                // c-1 and c, so a group costs five new reads (one column of five rows) where the row-wise walk of the unit-block
+                // kernels costs eight -- 45 instead of 72 reads per 4 x 8 positions.  The window passes need that: their
+                // half-sweeps carry units that share a bank pair, and at two passes per read the LDS pipe was their bottleneck.
+                // Three column buffers (previous, current, prefetched); the Xk ring holds two columns x four rows per slot.
+                constexpr int kBlocks = kRH / 4;
+                f2 cb[3][5];
+                unsigned ra[5];              // the lane's five tile rows of the row block (byte address of column -1)
+                auto rows_of_block = [&](int rb, unsigned (&r)[5]) {
+                    if constexpr (RING) {
+                        const unsigned bc = base[si][0] & 0xffffu;
+                        int sl = origin + (int)(base[si][0] >> 16) + 4 * rb;
+                        sl = sl >= a.erows ? sl - a.erows : sl;
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) {
+                            const int slk = sl + k >= a.erows ? sl + k - a.erows : sl + k;
+                            r[k] = (unsigned)slk * row_bytes + bc;
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 5; ++k) r[k] = base[si][0] + bufoff + (unsigned)(4 * rb + k) * row_bytes;
+                    }
+                };
+#pragma unroll
+                for (int rb = 0; rb < kBlocks; ++rb) {
+                    // (every row block starts with its own exposed read of columns -1 and 0: carrying the next block's row
+                    // addresses through the last group cost registers the 8-row kernel does not have)
+                    rows_of_block(rb, ra);
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        lds_read(cb[0][k], ra[k], 0);                    // column -1
+                        lds_read(cb[1][k], ra[k], kDF * 8);              // column 0
+                    }
+                    lgkm_wait0();
+#pragma unroll
+                    for (int c = 0; c < kRW; ++c) {
+                        f2(&prev)[5] = cb[c % 3];
+                        f2(&cur)[5] = cb[(c + 1) % 3];
+                        f2(&nxt)[5] = cb[(c + 2) % 3];
+                        if (c + 1 < kRW) {
+#pragma unroll
+                            for (int k = 0; k < 5; ++k) lds_read(nxt[k], ra[k], (c + 2) * (kDF * 8));       // column c + 1
+                        }
+                        f2 et[4];
+                        {
+                            const f2* pe1 = &cur[0]; const f2* pl1 = &prev[0]; const f2* pe0 = &cur[1]; const f2* pl0 = &prev[1];
+                            DAU_INTERP4(et[0], et[1], et[2], et[3], pe0, pl0, pe1, pl1,
+                                        bw[si][0][0], bw[si][0][0], bw[si][0][0], bw[si][0][0],
+                                        bw[si][0][1], bw[si][0][1], bw[si][0][1], bw[si][0][1]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int ld = rb * 4 + c / 2;                // Xk load of this column pair
+                        if (c % 2 == 0) x_wait<kXSlots - 1>();
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            const int abid = (c % 2) * 4 + p;
+                            acc[si][0][0] = mfma_bcast<kCBSZ>(xr[ld % kXSlots].x, et[p].x, acc[si][0][0], abid);
+                            acc[si][0][1] = mfma_bcast<kCBSZ>(xr[ld % kXSlots].y, et[p].y, acc[si][0][1], abid);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (c % 2 == 1) {
+                            constexpr int kLoads = kRH;               // loads per sweep
+                            if (ld + kXSlots < kLoads) x_fetch(xr[ld % kXSlots], xbase, ld + kXSlots, xv[si]);
+                            else x_fetch(xr[ld % kXSlots], xnext_sweep, ld + kXSlots - kLoads, vnext);
+                        }
+                        lgkm_wait0();
+                    }
+                }
+                continue;
+            }
             // The sweep over the region is fully unrolled (no back-edge copies).  Software pipeline over groups of GS positions:
             // at the END of a group one lgkmcnt(0) retires the error columns prefetched for the next group, which flew under
             // this group's work.  (Tried in round 3: the last group of a sweep requesting the first group of the item's next
@@ -1053,27 +1147,6 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                             l0[p][gp] = p > 0 ? eb[par][gp][1][p > 0 ? p - 1 : 0] : (gq == 0 ? epn[gp][1] : eb[par ^ 1][gp][1][GS - 1]);
                         }
                     }
-#define DAU_INTERP4(o0, o1, o2, o3, E0, L0, E1, L1, A0, A1, A2, A3, B0, B1, B2, B3)                                  \
-    asm volatile("v_pk_mul_f32 %0, %4, %20 op_sel_hi:[1,0]\n\t"                                                     \
-                 "v_pk_mul_f32 %1, %5, %21 op_sel_hi:[1,0]\n\t"                                                     \
-                 "v_pk_mul_f32 %2, %6, %22 op_sel_hi:[1,0]\n\t"                                                     \
-                 "v_pk_mul_f32 %3, %7, %23 op_sel_hi:[1,0]\n\t"                                                     \
-                 "v_pk_fma_f32 %0, %8, %20, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                                \
-                 "v_pk_fma_f32 %1, %9, %21, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                                \
-                 "v_pk_fma_f32 %2, %10, %22, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                               \
-                 "v_pk_fma_f32 %3, %11, %23, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                               \
-                 "v_pk_fma_f32 %0, %12, %24, %0 op_sel_hi:[1,0,1]\n\t"                                              \
-                 "v_pk_fma_f32 %1, %13, %25, %1 op_sel_hi:[1,0,1]\n\t"                                              \
-                 "v_pk_fma_f32 %2, %14, %26, %2 op_sel_hi:[1,0,1]\n\t"                                              \
-                 "v_pk_fma_f32 %3, %15, %27, %3 op_sel_hi:[1,0,1]\n\t"                                              \
-                 "v_pk_fma_f32 %0, %16, %24, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                               \
-                 "v_pk_fma_f32 %1, %17, %25, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                               \
-                 "v_pk_fma_f32 %2, %18, %26, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                               \
-                 "v_pk_fma_f32 %3, %19, %27, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]"                                    \
-                 : "=&v"(o0), "=&v"(o1), "=&v"(o2), "=&v"(o3)                                                         \
-                 : "v"(E0[0]), "v"(E0[1]), "v"(E0[2]), "v"(E0[3]), "v"(L0[0]), "v"(L0[1]), "v"(L0[2]), "v"(L0[3]),   \
-                   "v"(E1[0]), "v"(E1[1]), "v"(E1[2]), "v"(E1[3]), "v"(L1[0]), "v"(L1[1]), "v"(L1[2]), "v"(L1[3]),   \
-                   "v"(A0), "v"(A1), "v"(A2), "v"(A3), "v"(B0), "v"(B1), "v"(B2), "v"(B3))
 #if DAU_DOT_PRIO == 2
                     __builtin_amdgcn_s_setprio(1);
 #endif
