@@ -230,3 +230,17 @@ def test_batch_slabs_under_a_workspace_budget(mode, monkeypatch):
     assert plan.workspace_bytes(_capi.PASS_BACKWARD) < whole.workspace_bytes(_capi.PASS_BACKWARD)
     got = _run(plan, x, dy, w, mu1, mu2, dtype=dtype, calls=2)       # second call: hinted bucket, also in slabs
     _check_all(got, x, dy, w, mu1, mu2, "slabs/" + mode, io_rel=io_rel, io_floor=io_floor)
+
+
+def test_more_units_than_the_work_list_places_fall_back_to_the_direct_kernels():
+    """The window passes of the gather-dot place at most 16 units per channel pair (k_gather_dot.hip, kWlMaxUnits); a layer with
+    more units under a large kernel keeps the tiled gather-sum and takes the direct parameter-gradient kernels -- slower, same
+    results."""
+    from dau_conv import _capi
+    N, S, F, G, H, W, k = 2, 3, 8, 18, 24, 30, 33
+    x, dy, w, mu1, mu2 = _inputs(61, N, S, F, G, H, W, k, 15.0)
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, sigma_hint=0.5)
+    assert plan.info["algo_forward"] == _capi.ALGO_TILED and plan.info["algo_backward"] == _capi.ALGO_DIRECT, plan.info
+    _check_all(_run(plan, x, dy, w, mu1, mu2, calls=2), x, dy, w, mu1, mu2, "G=18 under kernel 33")
+    small = _capi.Plan(N, S, F, G, H, W, max_kernel_size=17, sigma_hint=0.5)       # buckets 4 and 8 have no such limit
+    assert small.info["algo_backward"] == _capi.ALGO_TILED
