@@ -488,7 +488,7 @@ int dau_conv_plan_get_info(const dau_conv_plan* plan, dau_conv_plan_info* info) 
     info->algo_backward = plan->algo_bwd;
     info->drop_last_col = plan->drop_col;
     info->drop_last_row = plan->drop_row;
-    info->gather_patch = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.tiles_x * 8 : 0;
+    info->gather_patch = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.tiles_x * plan->top().tiled_fwd.tile_w : 0;
     info->gather_stack = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.stack : 0;
     info->dot_windows = plan->algo_bwd == DAU_ALGO_TILED ? plan->top().tiled_dot.windows : 0;
     info->gather_windows = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.windows : 0;

@@ -18,7 +18,8 @@ struct TiledConfig {
     int stack;        // (image pair, patch) planes gathered per workgroup
     int patches;      // patches per image: big or odd-sized images are gathered patch by patch
     int rows, pitch;  // staged plane of a patch: rows = ph + 2R + 1, pitch (in positions) >= pw + 2R + 1 with pitch % 32 == 8
-    int tiles_x, tiles_y;   // 8x8 position tiles of a patch
+    int tiles_x, tiles_y;   // position tiles of a patch
+    int tile_w;             // their width: 8 (8 x 8 positions) or 32 (32 x 2)
     int fblock;       // out-channels per workgroup
     int variant;      // kernel instantiation id
     int debug;        // DAU_GATHER_DEBUG at plan creation (timing experiments)
@@ -100,6 +101,8 @@ struct WgradConfig {
                           // columns (an instantiated length)
     int splits;           // the image chunks are cut into `splits` ranges (partial sums per range)
     int Hp, Wp;           // plane of the intermediate fp32 copy (blur4_pack)
+    bool fused;           // XkT is written from x through the transposed bf16 copy (instantiated prefilter supports); else
+                          // through the fp32 copy of blur4_pack
 };
 bool dense_wgrad_configure(const Shape& sh, int blur_k, bool bf16, WgradConfig* cfg);
 size_t dense_wgrad_workspace_bytes(const WgradConfig& cfg);

@@ -25,6 +25,7 @@
 // both halves sits in LDS (pitch = 8 mod 16 positions: the four rows of a B fragment fall on different banks); per tap a
 // wave loads two A fragments from global memory (L1/L2 resident: 8 KB per tap and chunk for 256 channels) and NSUB B
 // fragments with ds_read_b128 at the tap's displacement, and issues 2*NSUB MFMAs.
+#include <cstdint>
 #include <cstdlib>
 
 #include "dau_tiled.hpp"
@@ -37,7 +38,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 namespace {
 
-constexpr int kDR = 4;                  // offset radius of the dense form
+#ifndef DAU_DENSE_R
+#define DAU_DENSE_R 4                   // (tools/build_variant.sh ... -DDAU_DENSE_R=8: the 18 x 18 form of bucket 8, timing experiment)
+#endif
+constexpr int kDR = DAU_DENSE_R;        // offset radius of the dense form
 constexpr int kDK = 2 * kDR + 2;        // taps per axis
 constexpr int kDTaps = kDK * kDK;
 constexpr int kDRows = 8;               // output rows per workgroup
@@ -111,6 +115,36 @@ __global__ void densify_units_kernel(const UnitRef* __restrict__ table, int Cin,
         }
         wd[idx] = (__bf16)v;
     }
+}
+
+// The same table, one thread per (input channel, output channel): its dense kernel is summed in LDS ([tap][thread] floats, zeroed,
+// then the four taps of each of its G units added) and written out tap by tap -- a wave = 4 output channels x the 16 input channels
+// of a chunk writes 128 contiguous bytes per tap.  G table reads per thread instead of G per OUTPUT ELEMENT (100 x fewer).
+constexpr int kScT = kDTaps <= 128 ? 64 : 32;             // threads per workgroup (the accumulators fill the static LDS limit otherwise)
+__global__ void __launch_bounds__(kScT) densify_units_scatter_kernel(const UnitRef* __restrict__ table, int Cin, int G, int Cout, int CoutP,
+                                                                     int nchunk, __bf16* __restrict__ wd, const Guard guard) {
+    __shared__ float acc[kDTaps * kScT];
+    if (!guard_pass(guard)) return;
+    constexpr int FPB = kScT / 16;                         // output channels per workgroup
+    const int tid = threadIdx.x, sl = tid & 15;
+    const int fq = blockIdx.x % (CoutP / FPB), chunk = blockIdx.x / (CoutP / FPB);
+    const int f = fq * FPB + (tid >> 4), c = chunk * 16 + sl;
+#pragma unroll 4
+    for (int tap = 0; tap < kDTaps; ++tap) acc[tap * kScT + tid] = 0.0f;
+    if (c < Cin && f < Cout) {
+        for (int g = 0; g < G; ++g) {                       // in the order of densify_units_kernel: the same fp32 sums
+            const UnitRef u = table[((long)c * G + g) * Cout + f];
+            const int ty = u.oy + kDR, tx = u.ox + kDR;
+            if (ty < 0 || ty + 1 >= kDK || tx < 0 || tx + 1 >= kDK) continue;   // (offsets are inside the bucket: guard of the call)
+            acc[(ty * kDK + tx) * kScT + tid] += u.w00;
+            acc[(ty * kDK + tx + 1) * kScT + tid] += u.w01;
+            acc[((ty + 1) * kDK + tx) * kScT + tid] += u.w10;
+            acc[((ty + 1) * kDK + tx + 1) * kScT + tid] += u.w11;
+        }
+    }
+    __bf16* dst = wd + ((long)chunk * kDTaps * CoutP + f) * 16 + sl;
+#pragma unroll 4
+    for (int tap = 0; tap < kDTaps; ++tap) dst[(long)tap * CoutP * 16] = (__bf16)acc[tap * kScT + tid];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -212,6 +246,137 @@ __global__ void __launch_bounds__(256) dense_stage_kernel(const DenseStageArgs a
 }
 
 // ------------------------------------------------------------------------------------------------
+// staging, fast form: bfloat16 input and an instantiated prefilter support K (taps in scalar registers, tap loops unrolled).
+// Workgroup = (image, group of 8 channels, band of rows, segment of <= 64 columns).  The raw window of the eight channels goes to
+// LDS as it is stored (bf16 bits, 16-byte pieces: a wave per channel, the pieces of consecutive rows are contiguous in HBM); then
+// every wave walks its share of the band's rows with lane = column: horizontal pass from LDS (one ds_read_u16 per tap and channel,
+// a wave reads 128 contiguous bytes), vertical pass over a register ring of K rows, one 16-byte unit = 8 channels per position.
+// Loads and stores are 16 bytes per lane and contiguous; the sums run in the order of dense_stage_kernel (bit-identical output).
+// ------------------------------------------------------------------------------------------------
+constexpr int kSP = 80;                   // LDS row of one channel: [8 spare | 64 columns | 8 spare] bf16 = ten 16-byte pieces
+struct DenseStageRowsArgs {
+    const unsigned short* in;
+    const float* taps;
+    __bf16* xd;
+    int N, C, H, W, mirrored;
+    int Hs, Ws, nchunk;
+    int RB, nbands, nsegs;   // rows per band, bands and 64-column segments per plane
+    int vec;                 // rows are whole 16-byte pieces (W % 8 == 0, base aligned)
+    Guard guard;
+};
+
+template <int K>
+__global__ void __launch_bounds__(512) dense_stage_rows_kernel(const DenseStageRowsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short rawl[];   // [row][8 channels][kSP]
+    if (!guard_pass(a.guard)) return;
+    constexpr int kr = (K - 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int t = blockIdx.x;
+    const int seg = t % a.nsegs; t /= a.nsegs;
+    const int band = t % a.nbands; t /= a.nbands;
+    const int grp = t % (2 * a.nchunk);
+    const int n = t / (2 * a.nchunk);
+    const int y0 = band * a.RB, y1 = y0 + a.RB < a.H ? y0 + a.RB : a.H;
+    const int x0 = seg * 64, x1 = x0 + 64 < a.W ? x0 + 64 : a.W;
+    const int lh = y1 - y0 + 2 * kr;
+    const long plane = (long)a.H * a.W;
+    // ---- raw window -> LDS: piece (r, q) of channel ch covers image row y0 - kr + r, columns x0 - 8 + 8q .. + 7
+    for (int ch = wave; ch < 8; ch += nw) {
+        const int c = grp * 8 + ch;
+        const unsigned short* src = a.in + ((long)n * a.C + (c < a.C ? c : 0)) * plane;
+        const int pieces = lh * (kSP / 8);
+        for (int i0 = lane; i0 < pieces; i0 += 64 * 4) {
+            uint4 v[4];
+            // branch-free loads (clamped address, masked value): a branch around a load makes hipcc wait for it at the join
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 64, r = i / (kSP / 8), q = i - r * (kSP / 8);
+                const int y = y0 - kr + r, xs = x0 - 8 + 8 * q;
+                const bool row_in = c < a.C && y >= 0 && y < a.H && i < pieces;
+                if (a.vec) {
+                    const bool ok = row_in && xs >= 0 && xs + 8 <= a.W;
+                    const uint4 w = *reinterpret_cast<const uint4*>(src + (ok ? (long)y * a.W + xs : 0));
+                    const unsigned m = ok ? 0xffffffffu : 0u;
+                    v[u] = make_uint4(w.x & m, w.y & m, w.z & m, w.w & m);
+                } else {
+                    unsigned e[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const bool ok = row_in && xs + k >= 0 && xs + k < a.W;
+                        e[k] = (unsigned)src[ok ? (long)y * a.W + xs + k : 0] & (ok ? 0xffffu : 0u);
+                    }
+                    v[u] = make_uint4(e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 64, r = i / (kSP / 8), q = i - r * (kSP / 8);
+                if (i < pieces) *reinterpret_cast<uint4*>(rawl + ((r * 8 + ch) * kSP + 8 * q)) = v[u];
+            }
+        }
+    }
+    // ---- zero border of the staged plane: what this workgroup's rows / columns touch outside the image
+    {
+        const int rs0 = band == 0 ? 0 : y0 + kDR, rs1 = band == a.nbands - 1 ? a.Hs : y1 + kDR;
+        const int cs0 = seg == 0 ? 0 : x0 + kDR, cs1 = seg == a.nsegs - 1 ? a.Ws : x1 + kDR;
+        const int cw = cs1 - cs0, cnt = (rs1 - rs0) * cw;
+        const float inv = 1.0f / (float)cw;
+        bf16x8* dst = reinterpret_cast<bf16x8*>(a.xd) + ((long)n * 2 * a.nchunk + grp) * a.Hs * a.Ws;
+        bf16x8 z;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) z[k] = (__bf16)0.0f;
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const int rr = fast_div(i, cw, inv), r = rs0 + rr, cc = cs0 + i - rr * cw;
+            if (r >= y0 + kDR && r < y1 + kDR && cc >= x0 + kDR && cc < x1 + kDR) continue;
+            dst[(long)r * a.Ws + cc] = z;
+        }
+    }
+    __syncthreads();
+    // ---- rows ya .. yb of this wave, lane = column
+    const int SR = (y1 - y0 + nw - 1) / nw;
+    const int ya = y0 + wave * SR, yb = ya + SR < y1 ? ya + SR : y1;
+    const int x = x0 + lane;
+    if (ya >= yb || x >= x1) return;
+    float gx[K], gy[K];
+    {
+        const float* px = a.taps + (a.mirrored ? kTapGXR : kTapGX) * kTapPitch;
+        const float* py = a.taps + (a.mirrored ? kTapGYR : kTapGY) * kTapPitch;
+#pragma unroll
+        for (int j = 0; j < K; ++j) { gx[j] = px[j]; gy[j] = py[j]; }
+    }
+    float ring[K][8];
+    const int nin = yb - ya + 2 * kr;                        // input rows ya - kr .. yb + kr - 1
+    bf16x8* dst = reinterpret_cast<bf16x8*>(a.xd) + (((long)n * 2 * a.nchunk + grp) * a.Hs + kDR) * a.Ws + kDR + x;
+    for (int s0 = 0; s0 < nin; s0 += K) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int s = s0 + j;
+            if (s < nin) {
+                const unsigned short* row = rawl + ((ya - y0 + s) * 8) * kSP + 8 + lane - kr;
+#pragma unroll
+                for (int ch = 0; ch < 8; ++ch) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < K; ++i) acc = fmaf(__uint_as_float((unsigned)row[ch * kSP + i] << 16), gx[i], acc);
+                    ring[j][ch] = acc;
+                }
+                if (s >= K - 1) {
+                    bf16x8 o;
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) {
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < K; ++i) acc = fmaf(ring[(j + 1 + i) % K][ch], gy[i], acc);
+                        o[ch] = (__bf16)acc;
+                    }
+                    dst[(long)(ya + s - (K - 1)) * a.Ws] = o;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // main kernel
 // ------------------------------------------------------------------------------------------------
 struct DenseArgs {
@@ -288,13 +453,15 @@ __global__ void __launch_bounds__(FT == 2 ? 256 : 512) dense_gather_kernel(const
     u32x4 win[PER];
     fetch(0, win);
     deposit(0, win);
-    bf16x8 af[5][FT];
+    constexpr int kRing = kDK % 5 == 0 ? 5 : 6;              // A buffers: a divisor of the taps per row (the ring index restarts per row)
+    static_assert(kDK % kRing == 0, "A ring");
+    bf16x8 af[kRing][FT];
     const bf16x8* wp = wsrc;                                  // tap 0 of chunk 0
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < kRing - 1; ++i)
 #pragma unroll
         for (int t2 = 0; t2 < FT; ++t2) af[i][t2] = wp[i * wtap + 64 * t2];
-    wp += 4 * wtap;                                           // next tap to request
+    wp += (kRing - 1) * wtap;                                 // next tap to request
     __syncthreads();
     for (int chunk = 0; chunk < a.nchunk; ++chunk) {
         const int buf = chunk & 1;
@@ -308,8 +475,8 @@ __global__ void __launch_bounds__(FT == 2 ? 256 : 512) dense_gather_kernel(const
             const unsigned brow = bbase + ty * P * 16;
 #pragma unroll
             for (int tx = 0; tx < kDK; ++tx) {
-                constexpr int kAhead = 4;
-                const int cur = tx % 5, nxt = (tx + kAhead) % 5, pb = tx & 1;
+                constexpr int kAhead = kRing - 1;
+                const int cur = tx % kRing, nxt = (tx + kAhead) % kRing, pb = tx & 1;
 #pragma unroll
                 for (int t2 = 0; t2 < FT; ++t2) af[nxt][t2] = wp[64 * t2];
                 wp += wtap;
@@ -389,12 +556,34 @@ void stage_tile(const DenseConfig& c, const DenseGeom& g, int* TR, int* TC, size
     // The kernel is latency bound: small tiles (about 22 x 22 positions, ~22 KiB of LDS, six workgroups per CU) beat big
     // ones although they filter more halo -- 65 x 65 planes: 16 x 65 tiles 1.32 ms, 22 x 22 tiles 0.70 ms (same box).
     int tr = (g.Hs + (g.Hs + 23) / 24 - 1) / ((g.Hs + 23) / 24), tc = (g.Ws + (g.Ws + 23) / 24 - 1) / ((g.Ws + 23) / 24);
-    tr = DAU_TUNE_INT("DAU_DENSE_STAGE_TR", tr);
-    tc = DAU_TUNE_INT("DAU_DENSE_STAGE_TC", tc);
+    const int want_tr = DAU_TUNE_INT("DAU_DENSE_STAGE_TR", 0), want_tc = DAU_TUNE_INT("DAU_DENSE_STAGE_TC", 0);
+    if (want_tr > 0) tr = want_tr;
+    if (want_tc > 0) tc = want_tc;
     auto bytes = [&](int r, int cc) { return (size_t)4 * (r + c.blur_k - 1) * ((cc + c.blur_k - 1) + cc) * 4; };
     while ((bytes(tr, tc) > 52 * 1024 || tr * tc > 5 * 256) && tr > 4) tr -= 4;
     while ((bytes(tr, tc) > 52 * 1024 || tr * tc > 5 * 256) && tc > 16) tc -= 16;
     *TR = tr; *TC = tc; *lds = bytes(tr, tc);
+}
+
+const void* stage_rows_for(int blur_k) {
+    switch (blur_k) {
+        case 3: return reinterpret_cast<const void*>(dense_stage_rows_kernel<3>);
+        case 5: return reinterpret_cast<const void*>(dense_stage_rows_kernel<5>);
+        case 7: return reinterpret_cast<const void*>(dense_stage_rows_kernel<7>);
+        case 9: return reinterpret_cast<const void*>(dense_stage_rows_kernel<9>);
+        default: return nullptr;                 // wider prefilters: dense_stage_kernel
+    }
+}
+// bands of rows whose raw window (eight channels, rows of kSP) stays below ~48 KiB of LDS: three workgroups per CU
+void stage_rows_plan(const DenseConfig& c, int* RB, int* nbands, size_t* lds) {
+    const int kr = (c.blur_k - 1) / 2;
+    int rows = 48 * 1024 / (8 * kSP * 2) - 2 * kr;
+    const int rb = DAU_TUNE_INT("DAU_DENSE_STAGE_RB", 0);
+    if (rb > 0) rows = rb;
+    rows = rows < 4 ? 4 : rows;
+    const int nb = (c.H + rows - 1) / rows;
+    *nbands = nb; *RB = (c.H + nb - 1) / nb;
+    *lds = (size_t)(*RB + 2 * kr) * 8 * kSP * 2;
 }
 
 }  // namespace
@@ -426,6 +615,7 @@ size_t dense_gather_workspace_bytes(const DenseConfig& c) {
 void dense_gather_init(const DenseConfig& c) {
     dispatch_dense(c.nsub, c.ftiles, nullptr, nullptr, 0);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dense_stage_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (stage_rows_for(c.blur_k)) (void)hipFuncSetAttribute(stage_rows_for(c.blur_k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 void dense_gather_prepare(hipStream_t st, const DenseConfig& c, const float* in, const float* filters, bool mirrored,
@@ -437,9 +627,25 @@ void dense_gather_prepare(hipStream_t st, const DenseConfig& c, const float* in,
     {
         const long total = (long)g.nchunk * kDTaps * g.CoutP * 16;
         const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-        hipLaunchKernelGGL(densify_units_kernel, dim3(grid), dim3(256), 0, st, table, c.Cin, c.G, c.Cout, g.CoutP, g.nchunk, wd, guard);
+        if (DAU_TUNE_INT("DAU_DENSE_SCATTER", 1))
+            hipLaunchKernelGGL(densify_units_scatter_kernel, dim3(g.nchunk * (g.CoutP / (kScT / 16))), dim3(kScT), 0, st, table, c.Cin, c.G, c.Cout,
+                               g.CoutP, g.nchunk, wd, guard);
+        else
+            hipLaunchKernelGGL(densify_units_kernel, dim3(grid), dim3(256), 0, st, table, c.Cin, c.G, c.Cout, g.CoutP, g.nchunk, wd, guard);
     }
-    {
+    if (stage_rows_for(c.blur_k) && c.bf16 && DAU_TUNE_INT("DAU_DENSE_STAGE_FAST", 1)) {
+        DenseStageRowsArgs s{};
+        s.in = reinterpret_cast<const unsigned short*>(in); s.taps = filters + kTaps1dOffset; s.xd = xd;
+        s.N = c.N; s.C = c.Cin; s.H = c.H; s.W = c.W; s.mirrored = mirrored ? 1 : 0;
+        s.Hs = g.Hs; s.Ws = g.Ws; s.nchunk = g.nchunk; s.guard = guard;
+        size_t lds;
+        stage_rows_plan(c, &s.RB, &s.nbands, &lds);
+        s.nsegs = (c.W + 63) / 64;
+        s.vec = c.W % 8 == 0 && reinterpret_cast<uintptr_t>(in) % 16 == 0;
+        const int threads = DAU_TUNE_INT("DAU_DENSE_STAGE_THREADS", 256);
+        void* args[] = {&s};
+        (void)hipLaunchKernel(stage_rows_for(c.blur_k), dim3(c.N * 2 * g.nchunk * s.nbands * s.nsegs), dim3(threads), args, lds, st);
+    } else {
         DenseStageArgs s{};
         s.in = in; s.taps = filters + kTaps1dOffset; s.xd = xd;
         s.N = c.N; s.C = c.Cin; s.H = c.H; s.W = c.W; s.k = c.blur_k; s.mirrored = mirrored ? 1 : 0; s.bf16 = c.bf16;

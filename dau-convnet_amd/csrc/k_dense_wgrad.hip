@@ -24,6 +24,7 @@
 // column): per column one new Xk fragment (a window of ten slides along the row; the row sits in LDS, loaded by
 // global_load_lds one row ahead and shared by the eight waves), one E' fragment (from global memory, six columns ahead)
 // and ten MFMAs.
+#include <cstdint>
 #include <cstdlib>
 
 #include "dau_tiled.hpp"
@@ -49,7 +50,9 @@ struct WgLayout { size_t xk_off, xkt_off, et_off, c_off, total; };
 WgLayout wg_layout(const WgradConfig& c) {
     WgLayout l{};
     size_t off = 0;
-    l.xk_off = off;  off += round_up((size_t)((c.sh.N + 1) / 2) * c.SB * 32 * c.Hp * c.Wp * 32, 256);
+    // fused staging: xT (one KiB per pixel of a 32-channel x 16-image block); else the fp32 copy of blur4_pack
+    l.xk_off = off;  off += c.fused ? round_up((size_t)c.SB * c.NC * c.sh.H * c.sh.W * 1024, 256)
+                                    : round_up((size_t)((c.sh.N + 1) / 2) * c.SB * 32 * c.Hp * c.Wp * 32, 256);
     l.xkt_off = off; off += round_up((size_t)kNumK * c.SB * c.NC * c.HsT * c.WsT * 1024, 256);
     l.et_off = off;  off += round_up((size_t)c.FB * c.NC * c.sh.H * c.nseg * c.WT * 1024 + (size_t)kWSlots * 1024, 256);   // + look-ahead past the end
     l.c_off = off;   off += round_up((size_t)c.splits * kNumK * kWD * kWD * c.SB * 32 * c.FB * 32 * 4, 256);
@@ -111,45 +114,291 @@ __global__ void __launch_bounds__(512) wg_stage_x_kernel(const WgStageXArgs a) {
     }
 }
 
-// dy[N,F,H,W] bf16 -> ET.  One workgroup per (fb, nc, row, run of 32 columns): 512 (image, channel) rows of 32 values -> LDS
-// -> 32 fragments of [32 f][16 n].  The unit_testing edge rule (last column / row of the error dropped) is applied here.
+// ------------------------------------------------------------------------------------------------
+// staging, fused form (instantiated prefilter supports): x -> xT (images innermost, bf16 as stored) -> XkT, without the fp32 copy.
+//   wg_transpose_x_kernel  x[N,S,H,W] bf16 -> xT[sb][nc][H][W][2][32 s][8 n]: the fragment order of XkT, one KiB per pixel
+//   wg_filter_kernel<K>    the four derivative filters applied IN that order: a fragment of XkT is an elementwise combination of
+//                          K x K fragments of xT, so every load and store is a contiguous half fragment (8 bytes per lane) whatever
+//                          the tap.  A wave owns (32 channels x 16 images, column, half of the images) and walks down the rows:
+//                          horizontal pass over the K neighbouring columns (read through L1/L2: the waves of the neighbouring columns
+//                          run on the same XCD), vertical pass over a register ring of K rows of the three horizontal results.
+// The sums run in the order of blur4_pack_kernel and are rounded to bfloat16 once, as wg_stage_x_kernel did: bit-identical XkT.
+// ------------------------------------------------------------------------------------------------
+struct WgTransposeArgs {
+    const unsigned short* x;
+    unsigned short* xt;
+    int N, S, SB, NC, H, W, nruns, vec;
+    Guard guard;
+};
+constexpr int kTPitch = 66;        // LDS row of one (image, channel): 64 columns + 2 (33 dwords: the 32 channels of a column read
+                                   // 32 different banks)
+__global__ void __launch_bounds__(512) wg_transpose_x_kernel(const WgTransposeArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[512 * kTPitch];   // [n*32 + s][column]
+    if (!guard_pass(a.guard)) return;
+    int t = blockIdx.x;
+    const int run = t % a.nruns; t /= a.nruns;
+    const int y = t % a.H; t /= a.H;
+    const int nc = t % a.NC;
+    const int sb = t / a.NC;
+    const int x0 = run * 64, cols = x0 + 64 < a.W ? 64 : a.W - x0;
+    // load: 512 rows of up to 64 values = 8 pieces of 16 bytes; consecutive lanes take consecutive pieces of a row
+    {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = threadIdx.x + u * 512, row = i >> 3, q = i & 7;
+            const int n = nc * 16 + (row >> 5), s = sb * 32 + (row & 31), xs = x0 + q * 8;
+            const bool in = n < a.N && s < a.S;
+            const unsigned short* src = a.x + (((long)(in ? n : 0) * a.S + (in ? s : 0)) * a.H + y) * a.W;
+            if (a.vec) {                                         // branch free: clamped address, masked value
+                const bool ok = in && xs + 8 <= a.W;
+                const uint4 w = *reinterpret_cast<const uint4*>(src + (ok ? xs : 0));
+                const unsigned m = ok ? 0xffffffffu : 0u;
+                v[u] = make_uint4(w.x & m, w.y & m, w.z & m, w.w & m);
+            } else {
+                unsigned e[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool ok = in && xs + k < a.W;
+                    e[k] = (unsigned)src[ok ? xs + k : 0] & (ok ? 0xffffu : 0u);
+                }
+                v[u] = make_uint4(e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = threadIdx.x + u * 512, row = i >> 3, q = i & 7;
+            unsigned* d = reinterpret_cast<unsigned*>(lds + row * kTPitch + q * 8);    // 4-byte aligned
+            d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+        }
+    }
+    __syncthreads();
+    // store: a wave writes one fragment per column: lane = (half, s) writes the 8 images of its half = 16 bytes
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, s = lane & 31;
+    for (int c = wave; c < cols; c += 8) {
+        unsigned e[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) e[n] = lds[((half * 8 + n) * 32 + s) * kTPitch + c];
+        uint4 o = make_uint4(e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16);
+        *reinterpret_cast<uint4*>(a.xt + ((((long)sb * a.NC + nc) * a.H + y) * a.W + x0 + c) * 512 + lane * 8) = o;
+    }
+}
+
+struct WgFilterArgs {
+    const unsigned short* xt;
+    unsigned short* xkt;
+    const float* taps;
+    int SB, NC, H, W, HsT, WsT;
+    int RB, nbands, ncolblk, nblocks;   // rows per band, bands, blocks of 2 staged columns, workgroups that have work
+    Guard guard;
+};
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    const __bf16 l = (__bf16)lo, h = (__bf16)hi;
+    return (unsigned)__builtin_bit_cast(unsigned short, l) | (unsigned)__builtin_bit_cast(unsigned short, h) << 16;
+}
+
+template <int K>
+__global__ void __launch_bounds__(256) wg_filter_kernel(const WgFilterArgs a) {
+    if (!guard_pass(a.guard)) return;
+    constexpr int kr = (K - 1) / 2;
+    // workgroups go to the eight XCDs round robin: give every XCD a contiguous range of the logical order, so that the column blocks
+    // of one (sb, nc, band) share an L2
+    const int per = gridDim.x >> 3;                              // the grid is a multiple of 8
+    int t = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (t >= a.nblocks) return;
+    const int cb = t % a.ncolblk; t /= a.ncolblk;
+    const int band = t % a.nbands; t /= a.nbands;
+    const int nc = t % a.NC;
+    const int sb = t / a.NC;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // everything below but `voff` is wave-uniform: scalar registers
+    const int half = wave & 1, cs = cb * 2 + (wave >> 1);        // staged column; image column x = cs - 4
+    if (cs >= a.WsT) return;
+    const int x = cs - 4;
+    const int y0 = band * a.RB, y1 = y0 + a.RB < a.H ? y0 + a.RB : a.H;
+    const int rs0 = band == 0 ? 0 : y0 + 4, rs1 = band == a.nbands - 1 ? a.HsT : y1 + 4;   // staged rows this wave writes
+    const unsigned voff = (unsigned)(half * 512 + lane * 8);     // this lane's 8 bytes of a fragment
+    const long kstride = (long)a.SB * a.NC * a.HsT * a.WsT * 1024;                         // one kind of XkT (bytes)
+    char* out = reinterpret_cast<char*>(a.xkt) + ((((long)sb * a.NC + nc) * a.HsT) * a.WsT + cs) * 1024;
+    const long rstride = (long)a.WsT * 1024;
+    auto store4 = [&](int r, uint2 w, uint2 m1, uint2 m2, uint2 sg) {
+        char* o = out + (long)r * rstride;
+        *reinterpret_cast<uint2*>(o + voff) = w;
+        *reinterpret_cast<uint2*>(o + kstride + voff) = m1;
+        *reinterpret_cast<uint2*>(o + 2 * kstride + voff) = m2;
+        *reinterpret_cast<uint2*>(o + 3 * kstride + voff) = sg;
+    };
+    const uint2 zero = make_uint2(0u, 0u);
+    if (x < 0 || x >= a.W) {                                     // border column
+        for (int r = rs0; r < rs1; ++r) store4(r, zero, zero, zero, zero);
+        return;
+    }
+    for (int r = rs0; r < y0 + 4; ++r) store4(r, zero, zero, zero, zero);
+    for (int r = y1 + 4; r < rs1; ++r) store4(r, zero, zero, zero, zero);
+    float gxt[K], axt[K], cxt[K], gyt[K], ayt[K], byt[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        gxt[j] = a.taps[kTapGX * kTapPitch + j]; axt[j] = a.taps[kTapAX * kTapPitch + j]; cxt[j] = a.taps[kTapCX * kTapPitch + j];
+        gyt[j] = a.taps[kTapGY * kTapPitch + j]; ayt[j] = a.taps[kTapAY * kTapPitch + j]; byt[j] = a.taps[kTapBY * kTapPitch + j];
+    }
+    // the K columns of the horizontal pass: clamped into the image, zero through a mask where they fall outside
+    const char* xbase = reinterpret_cast<const char*>(a.xt) + (((long)sb * a.NC + nc) * a.H) * a.W * 1024;
+    int colx[K];
+    unsigned cmask[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int xj = x + j - kr;
+        const bool in = xj >= 0 && xj < a.W;
+        colx[j] = in ? xj : x;
+        cmask[j] = in ? 0xffffffffu : 0u;
+    }
+    // input row s = image row y0 - kr + s; rows outside the image give zero horizontal results (their loads go to a valid row)
+    auto load_row = [&](int s, uint2 (&v)[K]) {
+        int yy = y0 - kr + s;
+        yy = yy < 0 ? 0 : (yy >= a.H ? a.H - 1 : yy);
+        const char* rowp = xbase + (long)yy * a.W * 1024;
+#pragma unroll
+        for (int j = 0; j < K; ++j) v[j] = *reinterpret_cast<const uint2*>(rowp + (long)colx[j] * 1024 + voff);
+    };
+    float ring[K][3][4];
+    auto horizontal = [&](int s, const uint2 (&cur)[K], float (&h)[3][4]) {
+        const int yy = y0 - kr + s;
+        const unsigned rmask = (yy >= 0 && yy < a.H) ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[q][e] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+            const unsigned m = cmask[i] & rmask;
+            const unsigned lo = cur[i].x & m, hi = cur[i].y & m;
+            const float v[4] = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
+                                __uint_as_float(hi & 0xffff0000u)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                h[0][e] = fmaf(v[e], gxt[i], h[0][e]);
+                h[1][e] = fmaf(v[e], axt[i], h[1][e]);
+                h[2][e] = fmaf(v[e], cxt[i], h[2][e]);
+            }
+        }
+    };
+    // two rows of loads in flight ahead of the one in use (a row's arithmetic is shorter than a trip to the L2)
+    uint2 nxt[K], nx2[K];
+    load_row(0, nxt);
+    load_row(1, nx2);
+    // prologue: the first K - 1 input rows only fill the ring
+#pragma unroll
+    for (int s = 0; s < K - 1; ++s) {
+        uint2 cur[K];
+#pragma unroll
+        for (int i = 0; i < K; ++i) { cur[i] = nxt[i]; nxt[i] = nx2[i]; }
+        load_row(s + 2, nx2);
+        horizontal(s, cur, ring[s]);
+    }
+    // K rows per trip: ring slot and tap order are compile-time; rows past the band are computed and not stored (RB is a multiple of K
+    // wherever the image allows)
+    const int nout = y1 - y0;
+    for (int o0 = 0; o0 < nout; o0 += K) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int s = o0 + j + K - 1;                        // input row; output row o0 + j
+            const int slot = (K - 1 + j) % K;
+            uint2 cur[K];
+#pragma unroll
+            for (int i = 0; i < K; ++i) { cur[i] = nxt[i]; nxt[i] = nx2[i]; }
+            load_row(s + 2, nx2);
+            horizontal(s, cur, ring[slot]);
+            float dw[4] = {0.0f, 0.0f, 0.0f, 0.0f}, d1[4] = {0.0f, 0.0f, 0.0f, 0.0f}, d2[4] = {0.0f, 0.0f, 0.0f, 0.0f},
+                  ds[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int i = 0; i < K; ++i) {
+                const int q = (slot + 1 + i) % K;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dw[e] = fmaf(ring[q][0][e], gyt[i], dw[e]);
+                    d1[e] = fmaf(ring[q][1][e], gyt[i], d1[e]);
+                    d2[e] = fmaf(ring[q][0][e], ayt[i], d2[e]);
+                    ds[e] = fmaf(ring[q][2][e], gyt[i], ds[e]);
+                    ds[e] = fmaf(ring[q][0][e], byt[i], ds[e]);
+                }
+            }
+            if (o0 + j < nout)
+                store4(y0 + o0 + j + 4, make_uint2(pack_bf16x2(dw[0], dw[1]), pack_bf16x2(dw[2], dw[3])),
+                       make_uint2(pack_bf16x2(d1[0], d1[1]), pack_bf16x2(d1[2], d1[3])),
+                       make_uint2(pack_bf16x2(d2[0], d2[1]), pack_bf16x2(d2[2], d2[3])),
+                       make_uint2(pack_bf16x2(ds[0], ds[1]), pack_bf16x2(ds[2], ds[3])));
+        }
+    }
+}
+
+// dy[N,F,H,W] bf16 -> ET.  One workgroup per (fb, nc, row, run of 64 columns): 512 (image, channel) rows of 64 values (16-byte
+// pieces, as wg_transpose_x_kernel) -> LDS -> one fragment of [32 f][16 n] per column.  The unit_testing edge rule (last column / row
+// of the error dropped) is applied here; the columns W .. WT'-1 are written as zeros.
 struct WgStageEArgs {
     const unsigned short* dy;
     __bf16* et;
-    int N, F, FB, NC, H, W, WT, drop_col, drop_row;
+    int N, F, FB, NC, H, W, WT, drop_col, drop_row, nruns, vec;
     Guard guard;
 };
 __global__ void __launch_bounds__(512) wg_stage_e_kernel(const WgStageEArgs a) {
-    __shared__ unsigned short lds[512 * 34];               // [n*32 + f][32 columns | 2]
+    __shared__ __attribute__((aligned(16))) unsigned short lds[512 * kTPitch];   // [n*32 + f][column]
     if (!guard_pass(a.guard)) return;
     int t = blockIdx.x;
-    const int runs = (a.WT + 31) / 32;
-    const int xr = t % runs; t /= runs;
+    const int run = t % a.nruns; t /= a.nruns;
     const int y = t % a.H; t /= a.H;
     const int nc = t % a.NC;
     const int fb = t / a.NC;
+    const int x0 = run * 64;
     const bool row_in = !(a.drop_row && y == a.H - 1);
     const int wlim = a.drop_col ? a.W - 1 : a.W;
-    for (int i = threadIdx.x; i < 512 * 32; i += blockDim.x) {
-        const int row = i >> 5, c = i & 31;
-        const int nl = row >> 5, fl = row & 31;
-        const int n = nc * 16 + nl, f = fb * 32 + fl, x = xr * 32 + c;
-        unsigned short v = 0;
-        if (row_in && n < a.N && f < a.F && x < wlim) v = a.dy[(((size_t)n * a.F + f) * a.H + y) * a.W + x];
-        lds[row * 34 + c] = v;
+    {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = threadIdx.x + u * 512, row = i >> 3, q = i & 7;
+            const int n = nc * 16 + (row >> 5), f = fb * 32 + (row & 31), xs = x0 + q * 8;
+            const bool in = row_in && n < a.N && f < a.F;
+            const unsigned short* src = a.dy + (((long)(in ? n : 0) * a.F + (in ? f : 0)) * a.H + y) * a.W;
+            if (a.vec) {
+                const bool ok = in && xs + 8 <= a.W;
+                const uint4 w = *reinterpret_cast<const uint4*>(src + (ok ? xs : 0));
+                unsigned d[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {                    // elements 2k, 2k+1: columns xs + 2k, xs + 2k + 1
+                    const unsigned m = (ok && xs + 2 * k < wlim ? 0xffffu : 0u) | (ok && xs + 2 * k + 1 < wlim ? 0xffff0000u : 0u);
+                    d[k] &= m;
+                }
+                v[u] = make_uint4(d[0], d[1], d[2], d[3]);
+            } else {
+                unsigned e[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const bool ok = in && xs + k < wlim;
+                    e[k] = (unsigned)src[ok ? xs + k : 0] & (ok ? 0xffffu : 0u);
+                }
+                v[u] = make_uint4(e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = threadIdx.x + u * 512, row = i >> 3, q = i & 7;
+            unsigned* d = reinterpret_cast<unsigned*>(lds + row * kTPitch + q * 8);
+            d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+        }
     }
     __syncthreads();
-    // fragment of column c: [32 f][16 n]; a thread writes one channel row of 16 images
-    for (int i = threadIdx.x; i < 32 * 32; i += blockDim.x) {
-        const int c = i >> 5, fl = i & 31;
-        const int x = xr * 32 + c;
-        if (x >= a.WT) continue;
-        unsigned short o[16];
+    // fragment of column c: [32 f][16 n]; lane = (f, half of the images) writes 16 bytes, a wave one fragment
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int f = lane >> 1, nh = lane & 1;
+    const int cols = x0 + 64 < a.WT ? 64 : a.WT - x0;
+    for (int c = wave; c < cols; c += 8) {
+        unsigned e[8];
 #pragma unroll
-        for (int n = 0; n < 16; ++n) o[n] = lds[(n * 32 + fl) * 34 + c];
-        unsigned short* dst = reinterpret_cast<unsigned short*>(a.et) + ((((size_t)fb * a.NC + nc) * a.H + y) * a.WT + x) * 512 + fl * 16;
-#pragma unroll
-        for (int n = 0; n < 16; ++n) dst[n] = o[n];
+        for (int n = 0; n < 8; ++n) e[n] = lds[((nh * 8 + n) * 32 + f) * kTPitch + c];
+        const uint4 o = make_uint4(e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16);
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned short*>(a.et) + ((((long)fb * a.NC + nc) * a.H + y) * a.WT + x0 + c) * 512 + lane * 8) = o;
     }
 }
 
@@ -314,6 +563,18 @@ const void* wg_gemm_for(int wt) {
 
 }  // namespace
 
+namespace {
+const void* wg_filter_for(int blur_k) {
+    switch (blur_k) {
+        case 3: return reinterpret_cast<const void*>(wg_filter_kernel<3>);
+        case 5: return reinterpret_cast<const void*>(wg_filter_kernel<5>);
+        case 7: return reinterpret_cast<const void*>(wg_filter_kernel<7>);
+        case 9: return reinterpret_cast<const void*>(wg_filter_kernel<9>);
+        default: return nullptr;                 // wider prefilters: blur4_pack_kernel + wg_stage_x_kernel
+    }
+}
+}  // namespace
+
 bool dense_wgrad_configure(const Shape& sh, int blur_k, bool bf16, WgradConfig* cfg) {
     if (!bf16) return false;
     WgradConfig c{};
@@ -329,7 +590,8 @@ bool dense_wgrad_configure(const Shape& sh, int blur_k, bool bf16, WgradConfig* 
     c.WsT = (int)round_up((size_t)c.nseg * c.WT + kWD - 1, 8);
     c.Hp = sh.H; c.Wp = (sh.W + 7) / 8 * 8;
     if (c.WT + kWD - 1 > kWDma * kWWaves || c.WT > kWMaxSteps) return false;   // two row segments of WT + 9 fragments in LDS
-    if (!blur4_pack_fits(blur_k, c.Hp, c.Wp)) return false;
+    c.fused = wg_filter_for(blur_k) != nullptr && DAU_TUNE_INT("DAU_WGRAD_FUSED_STAGE", 1) != 0;
+    if (!c.fused && !blur4_pack_fits(blur_k, c.Hp, c.Wp)) return false;
     const int fgroups = (c.FB + kWWaves - 1) / kWWaves;
     const int base = c.SB * fgroups * kWD * kNumK;
     int splits = (1024 + base - 1) / base;
@@ -342,7 +604,7 @@ bool dense_wgrad_configure(const Shape& sh, int blur_k, bool bf16, WgradConfig* 
 size_t dense_wgrad_workspace_bytes(const WgradConfig& c) { return wg_layout(c).total; }
 
 void dense_wgrad_init(const WgradConfig& c) {
-    blur4_pack_init(c.blur_k);
+    if (!c.fused) blur4_pack_init(c.blur_k);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wg_stage_x_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 65 * 4);
     (void)hipFuncSetAttribute(wg_gemm_for(c.WT), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
@@ -352,6 +614,32 @@ void dense_wgrad_run(hipStream_t st, const WgradConfig& c, const float* x, const
     const WgLayout l = wg_layout(c);
     char* ws = static_cast<char*>(workspace);
     const Shape& s = c.sh;
+    if (c.fused) {
+        unsigned short* xt = reinterpret_cast<unsigned short*>(ws + l.xk_off);
+        WgTransposeArgs t{};
+        t.x = reinterpret_cast<const unsigned short*>(x); t.xt = xt;
+        t.N = s.N; t.S = s.S; t.SB = c.SB; t.NC = c.NC; t.H = s.H; t.W = s.W; t.nruns = (s.W + 63) / 64;
+        t.vec = s.W % 8 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0;
+        t.guard = guard;
+        hipLaunchKernelGGL(wg_transpose_x_kernel, dim3(c.SB * c.NC * s.H * t.nruns), dim3(512), 0, st, t);
+        WgFilterArgs f{};
+        f.xt = xt; f.xkt = reinterpret_cast<unsigned short*>(ws + l.xkt_off); f.taps = filters + kTaps1dOffset;
+        f.SB = c.SB; f.NC = c.NC; f.H = s.H; f.W = s.W; f.HsT = c.HsT; f.WsT = c.WsT;
+        // bands of rows: enough workgroups for a few rounds of the chip (768 resident), at least 8 rows each
+        const int kr = (c.blur_k - 1) / 2;
+        f.ncolblk = c.WsT / 2;
+        int nbands = DAU_TUNE_INT("DAU_WGRAD_FILTER_BANDS", 0);
+        if (nbands <= 0) {
+            nbands = (4 * 768 + c.SB * c.NC * f.ncolblk - 1) / (c.SB * c.NC * f.ncolblk);
+            while (nbands > 1 && (s.H + nbands - 1) / nbands < 4 * kr + 2) --nbands;     // the halo rows are filtered twice
+        }
+        nbands = nbands < 1 ? 1 : (nbands > s.H ? s.H : nbands);
+        f.RB = (s.H + nbands - 1) / nbands; f.nbands = (s.H + f.RB - 1) / f.RB;
+        f.nblocks = c.SB * c.NC * f.nbands * f.ncolblk;
+        f.guard = guard;
+        void* args[] = {&f};
+        (void)hipLaunchKernel(wg_filter_for(c.blur_k), dim3((f.nblocks + 7) / 8 * 8), dim3(256), args, 0, st);
+    } else {
     float* xk = reinterpret_cast<float*>(ws + l.xk_off);
     launch_blur4_pack(st, x, filters, s.N, s.S, c.SB * 32, s.H, s.W, c.Hp, c.Wp, c.blur_k, true, xk, guard);
     {
@@ -361,12 +649,15 @@ void dense_wgrad_run(hipStream_t st, const WgradConfig& c, const float* x, const
         a.HsT = c.HsT; a.WsT = c.WsT; a.guard = guard;
         hipLaunchKernelGGL(wg_stage_x_kernel, dim3(c.SB * c.NC * c.HsT * (c.WsT / 8)), dim3(512), 256 * 65 * 4, st, a);
     }
+    }
     {
         WgStageEArgs a{};
         a.dy = reinterpret_cast<const unsigned short*>(dy); a.et = reinterpret_cast<__bf16*>(ws + l.et_off);
         a.N = s.N; a.F = s.F; a.FB = c.FB; a.NC = c.NC; a.H = s.H; a.W = s.W; a.WT = c.nseg * c.WT; a.drop_col = drop_col; a.drop_row = drop_row;
+        a.nruns = (c.nseg * c.WT + 63) / 64;
+        a.vec = s.W % 8 == 0 && reinterpret_cast<uintptr_t>(dy) % 16 == 0;
         a.guard = guard;
-        hipLaunchKernelGGL(wg_stage_e_kernel, dim3(c.FB * c.NC * s.H * ((c.nseg * c.WT + 31) / 32)), dim3(512), 0, st, a);
+        hipLaunchKernelGGL(wg_stage_e_kernel, dim3(c.FB * c.NC * s.H * a.nruns), dim3(512), 0, st, a);
     }
     {
         WgGemmArgs a{};

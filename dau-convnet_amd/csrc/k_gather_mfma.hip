@@ -57,7 +57,7 @@ struct Geometry {
     int ph, pw;               // patch (pixels)
     int npx, npy;             // patches per image
     int rows, pitch, cols;    // staged plane of one patch: rows x pitch positions, the first `cols` columns carry data
-    int tx, ty;               // regular 8x8 tiles of a patch
+    int tx, ty, tw;           // regular tiles of a patch (tw x 64/tw positions each)
     int edge;                 // 1: separate edge tiles for the extra row / column of Z; 0: regular tiles cover (H+1)x(W+1)
     int variant;              // row of kVariants, -1: no instantiated kernel fits
     int sk;                   // (image pair, patch) planes stacked per workgroup
@@ -68,7 +68,7 @@ struct Geometry {
     size_t plane_bytes;       // padded to 1 KiB (one global_load_lds wave instruction)
 };
 
-struct Variant { int tx, ty, pitch, edge, split, sk, plane_bytes, fb, tuning, nb = 2; };
+struct Variant { int tx, ty, pitch, edge, split, sk, plane_bytes, fb, tuning, nb = 2, tw = 8; };   // tw: tile width (8 x 8 or 32 x 2 positions)
 // instantiated kernels (add rows here and in the dispatch of tiled_gather_run)
 const Variant kVariants[] = {
     {7, 7, 72, 1, 2, 1, 0, 4, 0},       // 0: 56x56 patches, R=4
@@ -106,6 +106,13 @@ const Variant kVariants[] = {
     {4, 4, 104, 0, 1, 1, 0, 12, 0},     // 22: 31 pixel patches, R <= 28, twelve channels (512x512, bucket 18: 250 -> 242 ms per pass)
     {4, 4, 72, 0, 1, 1, 0, 12, 0},      // 23: 31 pixel patches, R <= 20, twelve channels on a pitch-72 plane: a third fewer staged
                                         //     bytes to write, fetch and hold than row 22 for the buckets that fit (16, 18, 20)
+    // Tiles of 32 x 2 positions (a half wave reads 32 consecutive positions: conflict free under any pitch): the 29 x 29 domain
+    // of a 28 pixel image is 15 such tiles (30 rows) instead of 16 tiles of 8 x 8 (32 rows), a 27 pixel image 14.  Measured
+    // (same box, 28x28 at 512 channels): 10.77 / 11.49 ms against 10.43 / 11.04 ms for row 21 although a sixteenth of the MFMAs is
+    // gone and ds_read_b64 runs at the same 2.25 clk for both lane maps (tools/microbench/lds_tile_shapes.hip): explicit request
+    // only (DAU_GATHER_VARIANT=24 / 25 in the tuning build)
+    {1, 15, 40, 0, 1, 1, 0, 12, 2, 2, 32},   // 24: one 28 / 29 pixel image, twelve channels
+    {1, 14, 40, 0, 1, 1, 0, 12, 2, 2, 32},   // 25: one 25..27 pixel image, twelve channels
 };
 
 // one (channel block, input channel) slice of the packed unit table: [G slots][fb channels][8 dwords]; window passes
@@ -146,8 +153,9 @@ Geometry make_geometry(int H, int W, int R, int G, int N, int Cout, int only = -
             cols = pw + 1 + 2 * R; rows = ph + 1 + 2 * R;
         } else {
             // regular tiles cover the (ph+1) x (pw+1) domain of Z: a whole image, or patches of 8*t - 1 pixels
-            ph = H < v.ty * 8 - 1 ? H : v.ty * 8 - 1; pw = W < v.tx * 8 - 1 ? W : v.tx * 8 - 1;
-            cols = v.tx * 8 + 2 * R; rows = v.ty * 8 + 2 * R;
+            const int th = 64 / v.tw;
+            ph = H < v.ty * th - 1 ? H : v.ty * th - 1; pw = W < v.tx * v.tw - 1 ? W : v.tx * v.tw - 1;
+            cols = v.tx * v.tw + 2 * R; rows = v.ty * th + 2 * R;
         }
         if (cols > v.pitch) continue;
         const size_t plane = round_up(((size_t)rows * v.pitch + (v.edge ? (size_t)(2 * R + 1) * rows : 0)) * 8, 1024);
@@ -172,7 +180,7 @@ Geometry make_geometry(int H, int W, int R, int G, int N, int Cout, int only = -
         if (g.variant >= 0 && cost >= best) continue;
         best = cost;
         g.variant = i; g.ph = ph; g.pw = pw; g.npx = npx; g.npy = npy; g.rows = rows; g.cols = cols; g.pitch = v.pitch;
-        g.tx = v.tx; g.ty = v.ty; g.edge = v.edge; g.sk = v.sk; g.fb = v.fb; g.nb = v.nb;
+        g.tx = v.tx; g.ty = v.ty; g.tw = v.tw; g.edge = v.edge; g.sk = v.sk; g.fb = v.fb; g.nb = v.nb;
     }
     }
     if (g.variant < 0) return g;
@@ -429,9 +437,12 @@ struct GatherArgs {
 //          gather the last unit of channel c-1 and all but the last unit of channel c -- so that after a barrier they start
 //          with tile reads whose addresses they already hold while their partners fetch table entries, and the two waves
 //          of a SIMD do not sit in their start-up at the same time (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
-template <int TX_, int TY_, int PITCH_, bool EDGE_, int SPLIT_, int SK_ = 1, int PB_ = 0, int FB_ = kFB, int NB_ = 2>
+// TW     : tile = TW x (64 / TW) positions: 8 x 8, or 32 x 2 (non-EDGE only)
+template <int TX_, int TY_, int PITCH_, bool EDGE_, int SPLIT_, int SK_ = 1, int PB_ = 0, int FB_ = kFB, int NB_ = 2, int TW_ = 8>
 struct GatherTraits {
     static constexpr int TX = TX_, TY = TY_, PITCH = PITCH_, SPLIT = SPLIT_, SK = SK_, PB = PB_, FB = FB_, NB = NB_;
+    static constexpr int TW = TW_, TH = 64 / TW_;
+    static_assert(TW_ == 8 || (TW_ == 32 && !EDGE_), "tile shapes: 8 x 8, or 32 x 2 without edge tiles");
     static constexpr bool LAGGED = NB_ == 3;
     static constexpr bool EDGE = EDGE_;
     static constexpr int kRegular = TX * TY;
@@ -444,12 +455,12 @@ struct GatherTraits {
     static constexpr int kThreads = kWaves * 64;
     static constexpr int kEpiF = 2;   // output channels assembled per epilogue round
     static_assert(SK == 1 || PB > 0, "stacked planes need a compile-time plane size");
-    static_assert((SK - 1) * PB + ((TY * 8 - 1) * PITCH + TX * 8) * 8 < 65536, "LDS immediates are 16 bits");
+    static_assert((SK - 1) * PB + ((TY * TH - 1) * PITCH + TX * TW) * 8 < 65536, "LDS immediates are 16 bits");
 };
 
-template <int TX, int PITCH>
+template <int TX, int PITCH, int TW>
 __device__ __forceinline__ constexpr unsigned tile_imm(int tile) {
-    return (unsigned)(((tile / TX) * 8 * PITCH + (tile % TX) * 8) * 8);
+    return (unsigned)(((tile / TX) * (64 / TW) * PITCH + (tile % TX) * TW) * 8);
 }
 
 // One unit for one part: every tile index (hence every LDS immediate) is a compile-time constant.
@@ -476,7 +487,7 @@ __device__ __forceinline__ void load_tile(f2& dst, unsigned addr, unsigned addr_
     constexpr int plane = TILE / T::kPlaneTiles, t = TILE % T::kPlaneTiles;
     constexpr unsigned poff = (unsigned)(plane * T::PB);
     if constexpr (t < T::kRegular)
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(poff + tile_imm<T::TX, T::PITCH>(t)) : "memory");
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(poff + tile_imm<T::TX, T::PITCH, T::TW>(t)) : "memory");
     else if constexpr (t == T::kRegular)
         asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr_e0), "n"(poff) : "memory");
     else
@@ -589,7 +600,7 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
 
     // H, W: the pixels one plane covers (a patch; the whole image when it is small enough)
     const int R = a.R, H = EDGE ? TY * 8 : a.ph, W = EDGE ? TX * 8 : a.pw;
-    const int ly = lane >> 3, lx = lane & 7;
+    const int ly = lane / T::TW, lx = lane % T::TW;
     const unsigned lane_base = (unsigned)(((ly + R) * PITCH + (lx + R)) * 8);
     // Edge tiles (the extra row / column of Z): tile E0 = the row y = H, x = 0..W-1, read from the plane (consecutive
     // lanes, consecutive addresses); tile E1 = the column x = W, y = 0..H, read from the column-major strip so that its
@@ -717,7 +728,7 @@ __device__ __forceinline__ void gather_body(const GatherArgs& a, char* smem, int
                     const int k = flat / T::kPlaneTiles, tile = flat % T::kPlaneTiles;
                     int y, x; bool ok;
                     if (flat >= T::kTiles) { y = 0; x = 0; ok = false; }
-                    else if (tile < T::kRegular) { y = (tile / TX) * 8 + ly; x = (tile % TX) * 8 + lx; ok = (y <= H) && (x <= W); }
+                    else if (tile < T::kRegular) { y = (tile / TX) * T::TH + ly; x = (tile % TX) * T::TW + lx; ok = (y <= H) && (x <= W); }
                     else if (tile == T::kRegular) { y = ey[0]; x = ex[0]; ok = evalid[0]; }
                     else { y = ey[1]; x = ex[1]; ok = evalid[1]; }
                     if (ok) {
@@ -798,6 +809,8 @@ void dispatch_variant(int variant, hipStream_t st, const GatherArgs* a, int grid
         case 21: launch_variant<GatherTraits<4, 4, 40, false, 1, 1, 0, 12>>(st, a, grid, lds); break;
         case 22: launch_variant<GatherTraits<4, 4, 104, false, 1, 1, 0, 12>>(st, a, grid, lds); break;
         case 23: launch_variant<GatherTraits<4, 4, 72, false, 1, 1, 0, 12>>(st, a, grid, lds); break;
+        case 24: launch_variant<GatherTraits<1, 15, 40, false, 1, 1, 0, 12, 2, 32>>(st, a, grid, lds); break;
+        case 25: launch_variant<GatherTraits<1, 14, 40, false, 1, 1, 0, 12, 2, 32>>(st, a, grid, lds); break;
         default: break;
     }
 }
@@ -840,7 +853,7 @@ bool tiled_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R
     TiledConfig c{};
     c.N = N; c.Cin = Cin; c.Cout = Cout; c.G = G; c.H = H; c.W = W; c.R = R; c.blur_k = blur_k;
     c.NP = (N + 1) / 2;
-    c.rows = g.rows; c.pitch = g.pitch; c.tiles_x = g.tx; c.tiles_y = g.ty; c.fblock = g.fb; c.variant = g.variant;
+    c.rows = g.rows; c.pitch = g.pitch; c.tiles_x = g.tx; c.tiles_y = g.ty; c.tile_w = g.tw; c.fblock = g.fb; c.variant = g.variant;
     c.patches = g.npx * g.npy; c.stack = g.sk; c.windows = g.nwin1 * g.nwin1;
     c.debug = DAU_TUNE_INT("DAU_GATHER_DEBUG", 0);
     c.bf16 = bf16 ? 1 : 0;

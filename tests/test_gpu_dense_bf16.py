@@ -108,6 +108,32 @@ def test_dense_parameter_gradients_against_oracle(shape, unit_testing):
         assert_parity(a.cpu().numpy(), b.cpu().numpy(), key + " (dense vs exact)", rel=2e-2, floor=4e-3)
 
 
+@pytest.mark.parametrize("sigma", [0.2, 0.35, 0.7, 1.0])
+@pytest.mark.parametrize("shape", [dict(N=3, S=20, F=40, G=4, H=30, W=45), dict(N=18, S=9, F=33, G=3, H=19, W=72)])
+def test_dense_forms_under_other_prefilter_supports(shape, sigma):
+    """The staging kernels of the dense forms are instantiated per prefilter support (3, 5, 7, 9 taps: dense_stage_rows_kernel,
+    wg_filter_kernel); wider prefilters (sigma 1.0: 11 taps) take the general staging kernels.  y, dx and the dense parameter
+    gradients at sigma 0.2 / 0.35 / 0.7 / 1.0 against the oracle at the bf16 bar; W = 45 takes the element-wise loads, W = 72 the
+    16-byte ones with two column segments."""
+    from dau_conv import _capi
+    N, S, F, G, H, W = (shape[q] for q in ("N", "S", "F", "G", "H", "W"))
+    xb, dyb, w, mu1, mu2 = _case(53, N, S, F, G, H, W, 3.99)
+    flags = _capi.FLAG_USE_INTERPOLATION | _capi.FLAG_IO_BF16 | _capi.FLAG_DENSE_BF16
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=sigma, flags=flags)
+    assert plan.info["gather_dense_bf16"] == 2
+    dev = lambda a: torch.from_numpy(a).cuda()
+    sig = torch.full((1, S, G, F), sigma, device="cuda")
+    y = plan.forward(xb.cuda(), dev(w), dev(mu1), dev(mu2), sig)
+    g = plan.backward(xb.cuda(), dyb.cuda(), dev(w), dev(mu1), dev(mu2), sig)
+    plan.check_status()
+    x32, dy32 = xb.float().numpy(), dyb.float().numpy()
+    assert_parity(y.float().cpu().numpy(), orc.forward(x32, w, mu1, mu2, sigma), "y sigma %g" % sigma, rel=2e-2, floor=4e-3)
+    want = orc.backward(x32, dy32, w, mu1, mu2, sigma)
+    assert_parity(g[0].float().cpu().numpy(), want["dx"], "dx sigma %g" % sigma, rel=2e-2, floor=4e-3)
+    for t, key in zip(g[1:], ("dw", "dmu1", "dmu2", "dsigma")):
+        assert_parity(t.cpu().numpy(), want[key], "%s sigma %g" % (key, sigma), rel=2e-2, floor=1e-2)
+
+
 def test_dense_bf16_under_a_larger_kernel_follows_the_offsets():
     """max_kernel_size 17 with the dense flag: calls with |mu| <= 4 take the dense GEMM (after the first call has left its
     hint), calls with larger offsets the exact gather of bucket 8; both match the oracle."""

@@ -297,6 +297,12 @@ def test_seeded_shapes_against_c_oracle(shape, algo):
     dict(N=2, W=64, H=40, S=4, F=26, G=5, k=49, m=23.5, variant=22, stack=1, patch=32),  # twelve channels, 31 pixel patches
     dict(N=2, W=70, H=40, S=4, F=26, G=5, k=37, m=17.9, variant=23, stack=1, patch=32),  # twelve channels on a pitch-72 plane (buckets <= 20)
     dict(N=3, W=33, H=64, S=3, F=12, G=9, k=41, m=19.9, variant=23, stack=1, patch=32),
+    # tiles of 32 x 2 positions: whole 28 / 27 pixel images in 15 / 14 tiles; larger images in patches of 31 x 29 / 31 x 27
+    dict(N=3, W=28, H=28, S=5, F=24, G=4, k=9, m=3, variant=24, stack=1, patch=32),
+    dict(N=4, W=29, H=26, S=3, F=17, G=3, k=9, m=3, variant=24, stack=1, patch=32),
+    dict(N=3, W=27, H=27, S=5, F=13, G=6, k=9, m=3, variant=25, stack=1, patch=32),
+    dict(N=2, W=70, H=61, S=3, F=12, G=2, k=9, m=3, variant=24, stack=1, patch=32),
+    dict(N=2, W=31, H=30, S=2, F=25, G=4, k=9, m=3, variant=25, stack=1, patch=32),
 ])
 def test_stacked_gather_variants(shape, monkeypatch):
     # the tuning build of the same sources: only it reads DAU_GATHER_VARIANT (at plan creation); the release library picks these
