@@ -15,7 +15,8 @@
 // K runs over the IMAGES innermost, so that a displacement only changes the position and every matrix fragment is one
 // aligned KiB whatever d is:
 //   XkT[k][sb][nc][H+9][WsT][2][32 s][8 n] bf16 the four derivative-filtered copies of x, staged position (r, c) = image
-//                                               (r-4, c-4), zero outside the image (wg_stage_x from blur4_pack's fp32 copy)
+//                                               (r-4, c-4), zero outside the image (wg_transpose_x + wg_filter<K> from x; prefilters
+//                                               wider than 9 taps: wg_stage_x from blur4_pack's fp32 copy)
 //   ET [fb][nc][H][WT'][32 f][16 n]      bf16   the error (unit_testing edge rule applied), zero for columns W..WT'-1 (WT' = whole
 //                                               row segments of an instantiated length)
 //   C  [split][k][10][10][SB*32][FB*32]  fp32   partial correlations of one range of image chunks
