@@ -475,7 +475,10 @@ __device__ __forceinline__ void lds_wait() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-constexpr int kBatch = 4;   // tiles per batch
+#ifndef DAU_GATHER_BATCH
+#define DAU_GATHER_BATCH 4      // (tools/build_variant.sh ... -DDAU_GATHER_BATCH=5: timing experiments)
+#endif
+constexpr int kBatch = DAU_GATHER_BATCH;   // tiles per batch
 
 // TILE: index into the wave's flat tile list = stacked plane * kPlaneTiles + tile of that plane
 template <class T, int TILE>
