@@ -113,6 +113,10 @@ const Variant kVariants[] = {
     // only (DAU_GATHER_VARIANT=24 / 25 in the tuning build)
     {1, 15, 40, 0, 1, 1, 0, 12, 2, 2, 32},   // 24: one 28 / 29 pixel image, twelve channels
     {1, 14, 40, 0, 1, 1, 0, 12, 2, 2, 32},   // 25: one 25..27 pixel image, twelve channels
+    // the twelve-channel rows with three plane buffers and lagged partner waves (one workgroup per CU: all its waves meet at every
+    // channel's barrier, nothing else on the CU fills the start-up after it)
+    {4, 4, 40, 0, 1, 1, 0, 12, 2, 3},        // 26: row 21 lagged
+    {4, 4, 72, 0, 1, 1, 0, 12, 2, 3},        // 27: row 23 lagged
 };
 
 // one (channel block, input channel) slice of the packed unit table: [G slots][fb channels][8 dwords]; window passes
@@ -814,6 +818,8 @@ void dispatch_variant(int variant, hipStream_t st, const GatherArgs* a, int grid
         case 23: launch_variant<GatherTraits<4, 4, 72, false, 1, 1, 0, 12>>(st, a, grid, lds); break;
         case 24: launch_variant<GatherTraits<1, 15, 40, false, 1, 1, 0, 12, 2, 32>>(st, a, grid, lds); break;
         case 25: launch_variant<GatherTraits<1, 14, 40, false, 1, 1, 0, 12, 2, 32>>(st, a, grid, lds); break;
+        case 26: launch_variant<GatherTraits<4, 4, 40, false, 1, 1, 0, 12, 3>>(st, a, grid, lds); break;
+        case 27: launch_variant<GatherTraits<4, 4, 72, false, 1, 1, 0, 12, 3>>(st, a, grid, lds); break;
         default: break;
     }
 }

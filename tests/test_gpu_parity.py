@@ -303,6 +303,11 @@ def test_seeded_shapes_against_c_oracle(shape, algo):
     dict(N=3, W=27, H=27, S=5, F=13, G=6, k=9, m=3, variant=25, stack=1, patch=32),
     dict(N=2, W=70, H=61, S=3, F=12, G=2, k=9, m=3, variant=24, stack=1, patch=32),
     dict(N=2, W=31, H=30, S=2, F=25, G=4, k=9, m=3, variant=25, stack=1, patch=32),
+    # the twelve-channel rows with lagged partner waves (three plane buffers)
+    dict(N=3, W=28, H=28, S=5, F=24, G=4, k=9, m=3, variant=26, stack=1, patch=32),
+    dict(N=3, W=27, H=27, S=4, F=13, G=1, k=9, m=3, variant=26, stack=1, patch=32),
+    dict(N=2, W=70, H=40, S=4, F=26, G=5, k=37, m=17.9, variant=27, stack=1, patch=32),
+    dict(N=3, W=33, H=64, S=3, F=12, G=9, k=41, m=19.9, variant=27, stack=1, patch=32),
 ])
 def test_stacked_gather_variants(shape, monkeypatch):
     # the tuning build of the same sources: only it reads DAU_GATHER_VARIANT (at plan creation); the release library picks these
