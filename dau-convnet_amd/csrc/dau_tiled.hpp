@@ -41,7 +41,7 @@ void tiled_gather_run(hipStream_t st, const TiledConfig& cfg, float* out, void* 
 void tiled_gather_init(const TiledConfig& cfg);
 
 // Densified bf16 gather-sum (k_dense_bf16.hip; DAU_FLAG_DENSE_BF16, offset bucket 4, bfloat16 activations): the units of
-// every (input, output) channel pair scattered into a dense 10 x 10 kernel, implicit GEMM on the bf16 matrix cores.
+// every (input, output) channel pair scattered into a dense 9 x 9 kernel, implicit GEMM on the bf16 matrix cores.
 struct DenseConfig {
     int N, Cin, Cout, G, H, W;
     int R, blur_k;
@@ -91,13 +91,13 @@ void blur4_pack_init(int blur_k);
 bool blur4_pack_fits(int blur_k, int Hp, int Wp);
 
 // Densified parameter gradients on the bf16 matrix cores (k_dense_wgrad.hip; DAU_FLAG_DENSE_BF16, bucket 4, bfloat16
-// activations, three or more units): C_k[d][s][f] = sum_{n,q} Xk[n,s,q+d] * E'[n,f,q] for the 10 x 10 displacements d as a GEMM
+// activations, three or more units): C_k[d][s][f] = sum_{n,q} Xk[n,s,q+d] * E'[n,f,q] for the 9 x 9 displacements d as a GEMM
 // with K = (image, position), then r_k[u] = sum_taps b_t(u) * C_k[o_u + t].
 struct WgradConfig {
     Shape sh;
     int blur_k;
     int SB, FB, NC;       // 32-channel blocks of S and F, 16-image chunks of N
-    int HsT, WsT, WT, nseg;   // staged Xk plane (H+9 rows, nseg*WT+9 columns rounded up to 8); a row is walked in nseg segments of WT
+    int HsT, WsT, WT, nseg;   // staged Xk plane (H+8 rows, nseg*WT+8 columns rounded up to 8); a row is walked in nseg segments of WT
                           // columns (an instantiated length)
     int splits;           // the image chunks are cut into `splits` ranges (partial sums per range)
     int Hp, Wp;           // plane of the intermediate fp32 copy (blur4_pack)

@@ -1,11 +1,11 @@
 // Densified gather-sum on the bf16 matrix cores (DAU_FLAG_DENSE_BF16; offsets within +-4 only).
 //
-//   out[n,f,y,x] = sum_{c} sum_{ty,tx < 10} Wd[f][c][ty][tx] * Xb[n,c, y+ty-4, x+tx-4]
+//   out[n,f,y,x] = sum_{c} sum_{ty,tx < 9} Wd[f][c][ty][tx] * Xb[n,c, y+ty-4, x+tx-4]
 //
-// The G units of every (input channel c, output channel f) pair are scattered into a dense 10 x 10 kernel
+// The G units of every (input channel c, output channel f) pair are scattered into a dense 9 x 9 kernel
 // (integer offsets -4..4 plus the second bilinear tap: Wd[f][c][oy+dy+4][ox+dx+4] += w * b_dydx) and the pass becomes an
-// implicit GEMM  M = output channels, N = pixels, K = input channels x 100 taps  on v_mfma_f32_32x32x16_bf16 (fp32
-// accumulation).  That is 100 / (4 G) times the FLOPs of the exact gather (k_gather_mfma.hip) at 16 x its matrix rate:
+// implicit GEMM  M = output channels, N = pixels, K = input channels x 81 taps  on v_mfma_f32_32x32x16_bf16 (fp32
+// accumulation).  That is 81 / (4 G) times the FLOPs of the exact gather (k_gather_mfma.hip) at 16 x its matrix rate:
 // SURVEY.md section 7 hard part (A), measured with the library convolution in tools/probe_densified_bf16.py (1.9 - 2.7 x
 // faster than the gather for the forward pass of BASELINE config 2).  It replaces the same reference code as the gather:
 // DAUConv_forward_pipeline_kernel + interleave_input_data_kernel + perpare_weights_and_offsets
@@ -21,12 +21,13 @@
 //   WD[chunk][tap][CoutP][16]      bf16: the dense kernel, 32 bytes per output channel (A fragments of the two lane halves).
 // Workgroup = 128 output channels x 8 rows x NSUB*8 columns, as 8 waves = 4 (32 channels each) x 2 (4 rows each), two per
 // SIMD (or 4 waves with two channel tiles each, FT = 2); a wave owns FT x NSUB accumulator tiles of 32 channels x (4 rows x
-// 8 columns).  Per chunk the 17 x (NSUB*8+9) window of
+// 8 columns).  Per chunk the 16 x (NSUB*8+8) window of
 // both halves sits in LDS (pitch = 8 mod 16 positions: the four rows of a B fragment fall on different banks); per tap a
 // wave loads two A fragments from global memory (L1/L2 resident: 8 KB per tap and chunk for 256 channels) and NSUB B
 // fragments with ds_read_b128 at the tap's displacement, and issues 2*NSUB MFMAs.
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "dau_tiled.hpp"
 
@@ -42,7 +43,11 @@ namespace {
 #define DAU_DENSE_R 4                   // (tools/build_variant.sh ... -DDAU_DENSE_R=8: the 18 x 18 form of bucket 8, timing experiment)
 #endif
 constexpr int kDR = DAU_DENSE_R;        // offset radius of the dense form
-constexpr int kDK = 2 * kDR + 2;        // taps per axis
+// Taps per axis: integer offsets -R .. R plus the second bilinear tap.  An offset of exactly +R has fraction 0, so the taps at
+// R + 1 carry the weight 0 for every unit a guarded call can see (|mu| <= R): the production form (R = 4) leaves that row and
+// column out -- 81 taps instead of 100.  (The R = 8 timing variant keeps the 18 x 18 form it was measured with.)
+constexpr int kDK = kDR == 4 ? 2 * kDR + 1 : 2 * kDR + 2;
+constexpr int kDSpan = kDK - 1;         // border of the staged plane and of the LDS window (positions)
 constexpr int kDTaps = kDK * kDK;
 constexpr int kDRows = 8;               // output rows per workgroup
 constexpr int kDFB = 128;               // output channels per workgroup
@@ -70,8 +75,8 @@ DenseGeom dense_geometry(const DenseConfig& c) {
     g.nsub = best;
     g.ncb = (sub + g.nsub - 1) / g.nsub;
     g.nrb = (c.H + kDRows - 1) / kDRows;
-    g.Hs = g.nrb * kDRows + 2 * kDR + 1;
-    g.Ws = g.ncb * g.nsub * 8 + 2 * kDR + 1;
+    g.Hs = g.nrb * kDRows + kDSpan;
+    g.Ws = g.ncb * g.nsub * 8 + kDSpan;
     g.nchunk = (c.Cin + 15) / 16;
     g.CoutP = (int)round_up(c.Cout, kDFB);
     g.xd_bytes = round_up((size_t)c.N * g.nchunk * 2 * g.Hs * g.Ws * 16, 256);
@@ -79,8 +84,8 @@ DenseGeom dense_geometry(const DenseConfig& c) {
     return g;
 }
 
-constexpr int lds_pitch(int nsub) {       // positions; = 8 (mod 16) and >= nsub*8 + 9
-    int p = nsub * 8 + 2 * kDR + 1;
+constexpr int lds_pitch(int nsub) {       // positions; = 8 (mod 16) and >= nsub*8 + 8
+    int p = nsub * 8 + kDSpan;
     while (p % 16 != 8) ++p;
     return p;
 }
@@ -119,7 +124,7 @@ __global__ void densify_units_kernel(const UnitRef* __restrict__ table, int Cin,
 
 // The same table, one thread per (input channel, output channel): its dense kernel is summed in LDS ([tap][thread] floats, zeroed,
 // then the four taps of each of its G units added) and written out tap by tap -- a wave = 4 output channels x the 16 input channels
-// of a chunk writes 128 contiguous bytes per tap.  G table reads per thread instead of G per OUTPUT ELEMENT (100 x fewer).
+// of a chunk writes 128 contiguous bytes per tap.  G table reads per thread instead of G per OUTPUT ELEMENT (81 x fewer).
 constexpr int kScT = kDTaps <= 128 ? 64 : 32;             // threads per workgroup (the accumulators fill the static LDS limit otherwise)
 __global__ void __launch_bounds__(kScT) densify_units_scatter_kernel(const UnitRef* __restrict__ table, int Cin, int G, int Cout, int CoutP,
                                                                      int nchunk, __bf16* __restrict__ wd, const Guard guard) {
@@ -135,11 +140,12 @@ __global__ void __launch_bounds__(kScT) densify_units_scatter_kernel(const UnitR
         for (int g = 0; g < G; ++g) {                       // in the order of densify_units_kernel: the same fp32 sums
             const UnitRef u = table[((long)c * G + g) * Cout + f];
             const int ty = u.oy + kDR, tx = u.ox + kDR;
-            if (ty < 0 || ty + 1 >= kDK || tx < 0 || tx + 1 >= kDK) continue;   // (offsets are inside the bucket: guard of the call)
-            acc[(ty * kDK + tx) * kScT + tid] += u.w00;
-            acc[(ty * kDK + tx + 1) * kScT + tid] += u.w01;
-            acc[((ty + 1) * kDK + tx) * kScT + tid] += u.w10;
-            acc[((ty + 1) * kDK + tx + 1) * kScT + tid] += u.w11;
+            // (a tap outside the kernel belongs to an offset of exactly +R, weight 0, or to a call whose guard does not pass)
+            const bool y0 = ty >= 0 && ty < kDK, y1 = ty + 1 >= 0 && ty + 1 < kDK, x0 = tx >= 0 && tx < kDK, x1 = tx + 1 >= 0 && tx + 1 < kDK;
+            if (y0 && x0) acc[(ty * kDK + tx) * kScT + tid] += u.w00;
+            if (y0 && x1) acc[(ty * kDK + tx + 1) * kScT + tid] += u.w01;
+            if (y1 && x0) acc[((ty + 1) * kDK + tx) * kScT + tid] += u.w10;
+            if (y1 && x1) acc[((ty + 1) * kDK + tx + 1) * kScT + tid] += u.w11;
         }
     }
     __bf16* dst = wd + ((long)chunk * kDTaps * CoutP + f) * 16 + sl;
@@ -393,8 +399,8 @@ template <int NSUB, int FT>
 __global__ void __launch_bounds__(FT == 2 ? 256 : 512) dense_gather_kernel(const DenseArgs a) {
     constexpr int kThreads = FT == 2 ? 256 : 512;
     constexpr int P = lds_pitch(NSUB);                       // LDS pitch (positions)
-    constexpr int WC = NSUB * 8 + 2 * kDR + 1;               // window columns
-    constexpr int WR = kDRows + 2 * kDR + 1;                 // window rows
+    constexpr int WC = NSUB * 8 + kDSpan;                    // window columns
+    constexpr int WR = kDRows + kDSpan;                      // window rows
     constexpr int HALF = WR * P * 16;                        // bytes of one half-plane window
     constexpr int BUF = 2 * HALF;
     constexpr int PIECES = 2 * WR * WC;                      // 16-byte pieces of a window
@@ -453,7 +459,12 @@ __global__ void __launch_bounds__(FT == 2 ? 256 : 512) dense_gather_kernel(const
     u32x4 win[PER];
     fetch(0, win);
     deposit(0, win);
-    constexpr int kRing = kDK % 5 == 0 ? 5 : 6;              // A buffers: a divisor of the taps per row (the ring index restarts per row)
+    // A buffers: a divisor of the taps per row (the ring index restarts per row); nine taps per row: a whole row ahead where the
+    // registers allow it (seven accumulator tiles: 236 of 256), else two taps ahead
+#ifndef DAU_DENSE_RING9
+#define DAU_DENSE_RING9 1
+#endif
+    constexpr int kRing = kDK % 5 == 0 ? 5 : kDK % 6 == 0 ? 6 : (DAU_DENSE_RING9 && NSUB * FT <= 7 ? 9 : 3);
     static_assert(kDK % kRing == 0, "A ring");
     bf16x8 af[kRing][FT];
     const bf16x8* wp = wsrc;                                  // tap 0 of chunk 0
@@ -470,13 +481,14 @@ __global__ void __launch_bounds__(FT == 2 ? 256 : 512) dense_gather_kernel(const
         bf16x8 bf[2][NSUB];
 #pragma unroll
         for (int j = 0; j < NSUB; ++j) bf[0][j] = *reinterpret_cast<const bf16x8*>(smem + bbase + (8 * j) * 16);
-#pragma unroll 1
-        for (int ty = 0; ty < kDK; ++ty) {
+        // one row of taps; PH = which of the two B buffers its first tap reads (rows of an odd number of taps alternate)
+        auto row = [&](int ty, auto ph) {
+            constexpr int PH = decltype(ph)::value;
             const unsigned brow = bbase + ty * P * 16;
 #pragma unroll
             for (int tx = 0; tx < kDK; ++tx) {
                 constexpr int kAhead = kRing - 1;
-                const int cur = tx % kRing, nxt = (tx + kAhead) % kRing, pb = tx & 1;
+                const int cur = tx % kRing, nxt = (tx + kAhead) % kRing, pb = (tx + PH) & 1;
 #pragma unroll
                 for (int t2 = 0; t2 < FT; ++t2) af[nxt][t2] = wp[64 * t2];
                 wp += wtap;
@@ -494,6 +506,17 @@ __global__ void __launch_bounds__(FT == 2 ? 256 : 512) dense_gather_kernel(const
                     for (int t2 = 0; t2 < FT; ++t2)
                         acc[t2][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cur][t2], bf[pb][j], acc[t2][j], 0, 0, 0);
             }
+        };
+        if constexpr (kDK & 1) {
+#pragma unroll 1
+            for (int ty = 0; ty + 1 < kDK; ty += 2) {
+                row(ty, std::integral_constant<int, 0>{});
+                row(ty + 1, std::integral_constant<int, 1>{});
+            }
+            row(kDK - 1, std::integral_constant<int, 0>{});      // (the next chunk starts with a fresh read into buffer 0)
+        } else {
+#pragma unroll 1
+            for (int ty = 0; ty < kDK; ++ty) row(ty, std::integral_constant<int, 0>{});
         }
         if (chunk + 1 < a.nchunk) {
             deposit(buf ^ 1, win);                             // nobody reads that buffer during this chunk
@@ -526,7 +549,7 @@ namespace {
 
 template <int NSUB, int FT>
 void launch_dense(hipStream_t st, const DenseArgs* a, int grid) {
-    constexpr size_t lds = 2 * 2 * (size_t)(kDRows + 2 * kDR + 1) * lds_pitch(NSUB) * 16;
+    constexpr size_t lds = 2 * 2 * (size_t)(kDRows + kDSpan) * lds_pitch(NSUB) * 16;
     auto kern = dense_gather_kernel<NSUB, FT>;
     if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return; }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(FT == 2 ? 256 : 512), lds, st, *a);
@@ -589,7 +612,7 @@ void stage_rows_plan(const DenseConfig& c, int* RB, int* nbands, size_t* lds) {
 }  // namespace
 
 bool dense_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, bool bf16, DenseConfig* cfg) {
-    if (R != kDR || !bf16) return false;          // the 10 x 10 dense kernel covers offsets within +-4; bf16 layers only
+    if (R != kDR || !bf16) return false;          // the 9 x 9 dense kernel covers offsets within +-4; bf16 layers only
     DenseConfig c{};
     c.N = N; c.Cin = Cin; c.Cout = Cout; c.G = G; c.H = H; c.W = W; c.R = R; c.blur_k = blur_k; c.bf16 = 1;
     const DenseGeom g = dense_geometry(c);

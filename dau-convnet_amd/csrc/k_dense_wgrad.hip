@@ -1,10 +1,10 @@
 // Densified parameter gradients on the bf16 matrix cores (DAU_FLAG_DENSE_BF16; offsets within +-4, three or more units).
 //
 //   r_k[s,g,f] = sum_{n,p} E'[n,f,p] * sum_{t in 2x2} b_t(s,g,f) * Xk[n,s, p + o + t]          k = w, mu1, mu2, sigma
-//             = sum_t b_t * C_k[o + t][s][f],      C_k[d][s][f] = sum_{n,p} Xk[n,s,p+d] * E'[n,f,p],   d in [-4, 5]^2
+//             = sum_t b_t * C_k[o + t][s][f],      C_k[d][s][f] = sum_{n,p} Xk[n,s,p+d] * E'[n,f,p],   d in [-4, 4]^2 (the second tap of an offset of exactly +4 has weight 0)
 //
-// The 100 cross-correlations C_k[d] do not depend on the units: 400 GEMMs  M = input channels, N = output channels,
-// K = (image, position)  on v_mfma_f32_32x32x16_bf16, 2*400*N*H*W*S*F FLOP whatever the unit count -- at the rate of the
+// The 81 cross-correlations C_k[d] do not depend on the units: 324 GEMMs  M = input channels, N = output channels,
+// K = (image, position)  on v_mfma_f32_32x32x16_bf16, 2*324*N*H*W*S*F FLOP whatever the unit count -- at the rate of the
 // dense gather-sum (k_dense_bf16.hip) that is the time the exact gather-dot (k_gather_dot.hip) needs for four units, so the
 // form is used from three units on (BASELINE config 2 has six).  It replaces the same reference code as the gather-dot:
 // DAUConv_bwd_multi_pipeline_kernel and its three preparation kernels
@@ -14,17 +14,18 @@
 //
 // K runs over the IMAGES innermost, so that a displacement only changes the position and every matrix fragment is one
 // aligned KiB whatever d is:
-//   XkT[k][sb][nc][H+9][WsT][2][32 s][8 n] bf16 the four derivative-filtered copies of x, staged position (r, c) = image
+//   XkT[k][sb][nc][H+8][WsT][2][32 s][8 n] bf16 the four derivative-filtered copies of x, staged position (r, c) = image
 //                                               (r-4, c-4), zero outside the image (wg_transpose_x + wg_filter<K> from x; prefilters
 //                                               wider than 9 taps: wg_stage_x from blur4_pack's fp32 copy)
 //   ET [fb][nc][H][WT'][32 f][16 n]      bf16   the error (unit_testing edge rule applied), zero for columns W..WT'-1 (WT' = whole
 //                                               row segments of an instantiated length)
-//   C  [split][k][10][10][SB*32][FB*32]  fp32   partial correlations of one range of image chunks
+//   C  [split][k][9][9][SB*32][FB*32]    fp32   partial correlations of one range of image chunks
 // wg_gemm: workgroup = (32 input channels, kind k, row displacement oy, range of image chunks) x 8 waves = 8 blocks of 32
-// output channels; a wave keeps the ten column displacements ox as ten 32 x 32 accumulators and walks (image chunk, row,
-// column): per column one new Xk fragment (a window of ten slides along the row; the row sits in LDS, loaded by
+// output channels; a wave keeps the nine column displacements ox as nine 32 x 32 accumulators and walks (image chunk, row,
+// column): per column one new Xk fragment (a window of nine slides along the row; the row sits in LDS, loaded by
 // global_load_lds one row ahead and shared by the eight waves), one E' fragment (from global memory, six columns ahead)
-// and ten MFMAs.
+// and nine MFMAs.
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 
@@ -39,7 +40,8 @@ typedef __attribute__((address_space(1))) const void* glb_ptr_t;
 
 namespace {
 
-constexpr int kWD = 10;            // displacements per axis: -4 .. 5
+constexpr int kWD = 9;             // displacements per axis: -4 .. 4 (the tap at +5 belongs to an offset of exactly +4: fraction 0,
+                                   // weight 0 -- wg_finish_kernel never reads it)
 constexpr int kWMaxSteps = 60;     // widest row (columns per row are straight-line code: see wg_gemm_kernel)
 constexpr int kWAhead = 5;         // E' fragments in flight ahead of the one in use
 constexpr int kWSlots = kWAhead + 1;
@@ -410,7 +412,7 @@ struct WgGemmArgs {
     const char* xkt;
     const char* et;
     float* c;
-    int SB, FB, NC, H, HsT, WsT, WT, nseg, rowf, splits, fgroups;   // WT: columns of a row segment, rowf: its Xk fragments (WT + 9)
+    int SB, FB, NC, H, HsT, WsT, WT, nseg, rowf, splits, fgroups;   // WT: columns of a row segment, rowf: its Xk fragments (WT + 8)
     Guard guard;
 };
 
@@ -438,7 +440,7 @@ constexpr int kWDma = 10;          // global_load_lds instructions per wave and 
 
 template <int NSTEP>
 __global__ void __launch_bounds__(kWWaves * 64) wg_gemm_kernel(const WgGemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // two row segments of WT + 9 Xk fragments
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // two row segments of WT + 8 Xk fragments
     if (!guard_pass(a.guard)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -461,7 +463,7 @@ __global__ void __launch_bounds__(kWWaves * 64) wg_gemm_kernel(const WgGemmArgs 
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.0f;
 
     // a "row" of the walk = one segment of WT columns of an image row (rows of more than 60 pixels are cut into segments;
-    // a segment needs the WT + 9 staged columns from its first one)
+    // a segment needs the WT + 8 staged columns from its first one)
     const unsigned row_bytes = (unsigned)a.rowf * 1024;
     const int per_chunk = a.H * a.nseg;
     const int rows = (nc1 - nc0) * per_chunk;
@@ -500,7 +502,7 @@ __global__ void __launch_bounds__(kWWaves * 64) wg_gemm_kernel(const WgGemmArgs 
         for (int i = 0; i < kWD - 1; ++i) win[i] = *reinterpret_cast<const bf16x8*>(arow + i * 1024);
 #pragma unroll
         for (int x = 0; x < NSTEP; ++x) {
-            // the window holds staged columns x .. x+9 (slot = column mod 10), eq[x mod 6] = E'(x)
+            // the window holds staged columns x .. x+8 (slot = column mod 9), eq[x mod 6] = E'(x)
             win[(x + kWD - 1) % kWD] = *reinterpret_cast<const bf16x8*>(arow + (x + kWD - 1) * 1024);
             WG_ELOAD(eq[(x + kWAhead) % kWSlots], lfrag, erow + (x + kWAhead) * 1024);     // (the buffer has slack past its end)
             if (x < kWAhead) wg_vmwait<kWAhead + kWDma>(); else wg_vmwait<kWAhead>();
@@ -526,25 +528,42 @@ __global__ void __launch_bounds__(kWWaves * 64) wg_gemm_kernel(const WgGemmArgs 
     }
 }
 
-// r4[k][(s*G+g)*F+f] = sum over the image ranges and the four bilinear taps of the unit
+// r4[k][(s*G+g)*F+f] = sum over the image ranges and the four bilinear taps of the unit.  The loads of four ranges (sixteen values)
+// are issued together; the sums run in double in the fixed order (range, tap), whatever the batching.
 __global__ void wg_finish_kernel(const float* __restrict__ c, const UnitRef* __restrict__ table, int S, int G, int F, int SP,
                                  int FP, int splits, float* __restrict__ r4, const Guard guard) {
     if (!guard_pass(guard)) return;
     const long units = (long)S * G * F;
+    const size_t plane = (size_t)SP * FP;                    // one displacement
     for (long u = blockIdx.x * (long)blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
         const int f = (int)(u % F), s = (int)(u / ((long)F * G));
         const UnitRef ur = table[u];
-        const float b[4] = {ur.w00, ur.w01, ur.w10, ur.w11};
         int dyi = ur.oy + 4, dxi = ur.ox + 4;
-        dyi = dyi < 0 ? 0 : (dyi > kWD - 2 ? kWD - 2 : dyi);        // (a guarded call never clamps: offsets within +-4)
-        dxi = dxi < 0 ? 0 : (dxi > kWD - 2 ? kWD - 2 : dxi);
+        dyi = dyi < 0 ? 0 : (dyi > kWD - 1 ? kWD - 1 : dyi);        // (a guarded call never clamps: offsets within +-4)
+        dxi = dxi < 0 ? 0 : (dxi > kWD - 1 ? kWD - 1 : dxi);
+        // displacement +5 = second tap of an offset of exactly +4: its weight is 0 and C does not hold it (the load goes to the
+        // unit's first tap instead and is multiplied by a zero weight)
+        const bool yin = dyi + 1 < kWD, xin = dxi + 1 < kWD;
+        const float b[4] = {ur.w00, xin ? ur.w01 : 0.0f, yin ? ur.w10 : 0.0f, (xin && yin) ? ur.w11 : 0.0f};
+        const size_t o00 = (size_t)(dyi * kWD + dxi) * plane;
+        const size_t off[4] = {o00, xin ? o00 + plane : o00, yin ? o00 + kWD * plane : o00, (xin && yin) ? o00 + (kWD + 1) * plane : o00};
+        const float* cu = c + (size_t)s * FP + f;
         for (int k = 0; k < kNumK; ++k) {
             double sum = 0.0;
-            for (int sp = 0; sp < splits; ++sp) {
-                const float* ck = c + (((size_t)sp * kNumK + k) * kWD * kWD) * SP * FP + (size_t)s * FP + f;
+            for (int sp0 = 0; sp0 < splits; sp0 += 4) {
+                float v[4][4];
 #pragma unroll
-                for (int tp = 0; tp < 4; ++tp)
-                    sum += (double)b[tp] * (double)ck[(size_t)((dyi + (tp >> 1)) * kWD + dxi + (tp & 1)) * SP * FP];
+                for (int q = 0; q < 4; ++q) {
+                    const int sp = sp0 + q < splits ? sp0 + q : splits - 1;          // (past the end: a valid range, not added)
+                    const float* ck = cu + (((size_t)sp * kNumK + k) * kWD * kWD) * plane;
+#pragma unroll
+                    for (int tp = 0; tp < 4; ++tp) v[q][tp] = ck[off[tp]];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (sp0 + q < splits)
+#pragma unroll
+                        for (int tp = 0; tp < 4; ++tp) sum += (double)b[tp] * (double)v[q][tp];
             }
             r4[(size_t)k * units + u] = (float)sum;
         }
@@ -590,13 +609,25 @@ bool dense_wgrad_configure(const Shape& sh, int blur_k, bool bf16, WgradConfig* 
     c.HsT = sh.H + kWD - 1;
     c.WsT = (int)round_up((size_t)c.nseg * c.WT + kWD - 1, 8);
     c.Hp = sh.H; c.Wp = (sh.W + 7) / 8 * 8;
-    if (c.WT + kWD - 1 > kWDma * kWWaves || c.WT > kWMaxSteps) return false;   // two row segments of WT + 9 fragments in LDS
+    if (c.WT + kWD - 1 > kWDma * kWWaves || c.WT > kWMaxSteps) return false;   // two row segments of WT + 8 fragments in LDS
     c.fused = wg_filter_for(blur_k) != nullptr && DAU_TUNE_INT("DAU_WGRAD_FUSED_STAGE", 1) != 0;
     if (!c.fused && !blur4_pack_fits(blur_k, c.Hp, c.Wp)) return false;
     const int fgroups = (c.FB + kWWaves - 1) / kWWaves;
     const int base = c.SB * fgroups * kWD * kNumK;
+    // ranges of image chunks: about four workgroups per CU or more, and among the counts that divide the chunks evenly the one whose
+    // grid wastes the least of its last round of 256 workgroups (one per CU: two rows of Xk fill the LDS)
     int splits = (1024 + base - 1) / base;
     splits = splits < 1 ? 1 : (splits > c.NC ? c.NC : splits);
+    {
+        double best = 1e30;
+        int pick = splits;
+        for (int sp = splits; sp <= c.NC && sp <= 4 * splits; ++sp) {
+            if (c.NC % sp) continue;
+            const double wgs = (double)base * sp, waste = std::ceil(wgs / 256.0) * 256.0 / wgs;
+            if (waste < best - 0.02) { best = waste; pick = sp; }
+        }
+        if (best < 1e30) splits = pick;
+    }
     c.splits = splits;
     *cfg = c;
     return true;
