@@ -396,9 +396,9 @@ def main():
         peak, roof_note = FP32_PEAK_TFLOPS, None
         dense_level = int(plan.info.get("gather_dense_bf16", 0)) if dense else 0
         if (dense_level >= 1 and dominant != "gather_dot") or (dense_level == 2 and dominant == "gather_dot"):
-            # the pass ran in its densified form on the bf16 matrix cores: price the FLOPs that form executes (100 taps per
-            # (input, output) channel pair and pixel; 400 for the four parameter-gradient kinds) against the bf16 roof
-            taps = 400.0 if dominant == "gather_dot" else 100.0
+            # the pass ran in its densified form on the bf16 matrix cores: price the FLOPs that form executes (9 x 9 = 81 taps per
+            # (input, output) channel pair and pixel; 324 for the four parameter-gradient kinds) against the bf16 roof
+            taps = 324.0 if dominant == "gather_dot" else 81.0
             ach = 2.0 * taps * N * H * W * S * F / (kern[dominant]["avg_ms"] * 1e-3) / 1e12
             peak = BF16_PEAK_TFLOPS
             roof_note = ("densified bf16 form: achieved = executed dense FLOPs (2*%d*N*H*W*S*F) / time against the dense bf16 "

@@ -1,5 +1,5 @@
 """GPU: the densified bf16 gather-sum (DAU_FLAG_DENSE_BF16 + DAU_FLAG_IO_BF16, k_dense_bf16.hip): for calls whose offsets lie
-within +-4 the two gather-sum passes (y and dx) run as an implicit GEMM on the bf16 matrix cores over a dense 10 x 10
+within +-4 the two gather-sum passes (y and dx) run as an implicit GEMM on the bf16 matrix cores over a dense 9 x 9
 kernel per channel pair.  Bar (SURVEY.md 8d, bf16 configuration): 2e-2 relative + 4e-3 of the max-norm against the fp32
 oracle fed the bf16-rounded inputs; the parameter gradients do not use the dense form and keep the fp32 bar."""
 import numpy as np
@@ -62,7 +62,7 @@ def test_dense_bf16_gather_against_oracle(shape):
     from dau_conv import _capi
     N, S, F, G, H, W = (shape[q] for q in ("N", "S", "F", "G", "H", "W"))
     xb, dyb, w, mu1, mu2 = _case(41, N, S, F, G, H, W, 3.99)
-    mu1.flat[0] = 3.99; mu2.flat[0] = -3.99; mu1.flat[1] = -4.0; mu2.flat[1] = 4.0       # the corners of the 10 x 10 kernel
+    mu1.flat[0] = 3.99; mu2.flat[0] = -3.99; mu1.flat[1] = -4.0; mu2.flat[1] = 4.0       # the corners of the 9 x 9 kernel (and the +5 tap of weight 0 it leaves out)
     flags = _capi.FLAG_USE_INTERPOLATION | _capi.FLAG_IO_BF16 | _capi.FLAG_DENSE_BF16
     plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=flags)
     # three or more units: the parameter gradients take the dense form too
