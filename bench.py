@@ -76,6 +76,9 @@ def parse_args():
                     help="storage type of x, y, dy, dx (BASELINE config 2 names bf16); arithmetic is fp32 either way")
     ap.add_argument("--dense", action="store_true",
                     help="with --io bf16: DAU_FLAG_DENSE_BF16 (gather-sum passes of calls with |mu| <= 4 as a densified bf16 MFMA GEMM)")
+    ap.add_argument("--no-dsigma", action="store_true",
+                    help="the step does not ask for dsigma (need mask of a layer whose sigma is not trained: the reference's default, "
+                         "dau_sigma_trainable=False); a side line, never the headline: BASELINE's step has all five gradients")
     ap.add_argument("--graph", action="store_true",
                     help="capture one step into a HIP graph and time its replays (single rank; no per-kernel events, so the "
                          "line carries no roofline object: a launch-overhead probe for the small workloads)")
@@ -271,6 +274,7 @@ def main():
     exchange = OverlappedBackward((1, S, G, F), dev) if use_dist else None
 
     last_grads = [None]
+    need_mask = _capi.NEED_ALL & ~_capi.NEED_DSIGMA if args.no_dsigma else _capi.NEED_ALL
 
     def step():
         y = plan.forward(x, w, mu1, mu2, sigma)
@@ -282,7 +286,7 @@ def main():
                               lambda sums: plan.finalize_param_grads(sums, w))
             exchange.wait()
         else:
-            last_grads[0] = plan.backward(x, dy, w, mu1, mu2, sigma)
+            last_grads[0] = plan.backward(x, dy, w, mu1, mu2, sigma, need_mask=need_mask)
             dx = last_grads[0][0]
         return y, dx
 
@@ -398,7 +402,7 @@ def main():
         if (dense_level >= 1 and dominant != "gather_dot") or (dense_level == 2 and dominant == "gather_dot"):
             # the pass ran in its densified form on the bf16 matrix cores: price the FLOPs that form executes (9 x 9 = 81 taps per
             # (input, output) channel pair and pixel; 324 for the four parameter-gradient kinds) against the bf16 roof
-            taps = 324.0 if dominant == "gather_dot" else 81.0
+            taps = (243.0 if args.no_dsigma else 324.0) if dominant == "gather_dot" else 81.0
             ach = 2.0 * taps * N * H * W * S * F / (kern[dominant]["avg_ms"] * 1e-3) / 1e12
             peak = BF16_PEAK_TFLOPS
             roof_note = ("densified bf16 form: achieved = executed dense FLOPs (2*%d*N*H*W*S*F) / time against the dense bf16 "
@@ -488,6 +492,7 @@ def main():
                    config=dict(workload=wl["label"] + (" [bf16 activations in HBM]" if args.io == "bf16" else "") +
                                (" [offsets: %s instead of U(-m,m)]" % args.offsets if args.offsets != "uniform" else "") +
                                (" [gather-sum passes%s as densified bf16 MFMA GEMM]" % (" and parameter gradients" if dense and int(plan.info.get("gather_dense_bf16", 0)) == 2 else "") if dense else "") +
+                               (" [SIDE LINE: the step does not ask for dsigma (dx, dw, dmu1, dmu2 only)]" if args.no_dsigma else "") +
                                (" [one step captured into a HIP graph, replays timed]" if args.graph and not use_dist else "") +
                                ("" if backend == "nccl" else " [REHEARSAL: %s backend, ranks share GPUs]" % backend),
                                global_batch=N * world, parallelism="dp%d" % world,

@@ -562,8 +562,9 @@ int dau_conv_forward(const dau_conv_plan* p, void* stream, const float* x, const
 namespace {
 
 // raw parameter-gradient sums r4[k][s][g][f] = offset_and_dot(x * D_k, dy') with bare bilinear factors
+// kinds: 4, or 3 when the caller does not want dsigma (only the dense form computes fewer: its GEMMs are per kind)
 int run_param_sums(const dau_conv_plan* p, hipStream_t st, const float* x, const float* dy, const float* mu1,
-                   const float* mu2, const BwdWs& ws, float* r4) {
+                   const float* mu2, const BwdWs& ws, float* r4, int kinds) {
     const Shape& s = p->sh;
     const int flags = p->d.flags;
     launch_prepare_units(st, nullptr, mu1, mu2, s, p->d.number_units_ignore, flags, p->bucket, false, ws.table_bare,
@@ -578,7 +579,7 @@ int run_param_sums(const dau_conv_plan* p, hipStream_t st, const float* x, const
             const TiledDotConfig& cfg = bs.tiled_dot;
             if (bs.wgrad_ok) {                                                 // bf16 layer, offsets within +-4, many units
                 ProfScope prof(p, 2, st);
-                dense_wgrad_run(st, bs.wgrad, x, dy, ws.filters, ws.table_bare, p->drop_col, p->drop_row, r4, ws.tiled_dot, cand[ci].guard);
+                dense_wgrad_run(st, bs.wgrad, x, dy, ws.filters, ws.table_bare, p->drop_col, p->drop_row, r4, ws.tiled_dot, cand[ci].guard, kinds);
                 continue;
             }
             for (int n0 = 0; n0 < s.N; n0 += bs.slab_dot) {                // the sums of the slabs add up in r4
@@ -625,7 +626,7 @@ int dau_conv_backward(const dau_conv_plan* p, void* stream, const float* x, cons
 
     const int param_mask = DAU_NEED_DW | DAU_NEED_DMU1 | DAU_NEED_DMU2 | DAU_NEED_DSIGMA;
     if (need_mask & param_mask) {
-        run_param_sums(p, st, x, dy, mu1, mu2, ws, ws.r4);
+        run_param_sums(p, st, x, dy, mu1, mu2, ws, ws.r4, (need_mask & DAU_NEED_DSIGMA) ? 4 : 3);
         launch_finalize_grads(st, ws.r4, w, s, p->d.number_units_ignore, p->d.mu_learning_rate_factor, need_mask,
                               flags & DAU_FLAG_SINGLE_DIM_KERNEL, dw, dmu1, dmu2, dsigma);
     }
@@ -679,7 +680,7 @@ int dau_conv_backward_param_sums(const dau_conv_plan* p, void* stream, const flo
     if (int rc = ensure_attrs(p)) return rc;
     DAU_HIP(hipMemsetAsync(ws.status, 0, sizeof(Status), st));
     launch_synth_filters(st, sigma, p->blur_k, p->d.flags, ws.filters);
-    run_param_sums(p, st, x, dy, mu1, mu2, ws, sums_out);
+    run_param_sums(p, st, x, dy, mu1, mu2, ws, sums_out, 4);
     DAU_HIP(hipPeekAtLastError());
     return DAU_OK;
 }

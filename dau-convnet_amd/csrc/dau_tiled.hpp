@@ -107,8 +107,10 @@ struct WgradConfig {
 bool dense_wgrad_configure(const Shape& sh, int blur_k, bool bf16, WgradConfig* cfg);
 size_t dense_wgrad_workspace_bytes(const WgradConfig& cfg);
 void dense_wgrad_init(const WgradConfig& cfg);
-// r4[k][s][g][f] = raw parameter-gradient sums; x, dy bfloat16 NCHW; table = bare unit table [S][G][F]
+// r4[k][s][g][f] = raw parameter-gradient sums; x, dy bfloat16 NCHW; table = bare unit table [S][G][F].  nk: kinds computed (w, mu1,
+// mu2, sigma in this order): 3 leaves the sigma block of r4 untouched (a caller that does not want dsigma; the reference's
+// last_k_optional: base_dau_conv_layer.hpp:213, src/dau_conv/dau_conv_impl/dau_conv_backward.cpp:219)
 void dense_wgrad_run(hipStream_t st, const WgradConfig& cfg, const float* x, const float* dy, const float* filters,
-                     const UnitRef* table, int drop_col, int drop_row, float* r4, void* workspace, const Guard& guard);
+                     const UnitRef* table, int drop_col, int drop_row, float* r4, void* workspace, const Guard& guard, int nk);
 
 }  // namespace dau

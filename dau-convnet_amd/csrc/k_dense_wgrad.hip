@@ -194,6 +194,7 @@ struct WgFilterArgs {
     const float* taps;
     int SB, NC, H, W, HsT, WsT;
     int RB, nbands, ncolblk, nblocks;   // rows per band, bands, blocks of 2 staged columns, workgroups that have work
+    int nk;                             // kinds wanted: 4, or 3 = without the sigma kind (the last one)
     Guard guard;
 };
 
@@ -226,12 +227,13 @@ __global__ void __launch_bounds__(256) wg_filter_kernel(const WgFilterArgs a) {
     const long kstride = (long)a.SB * a.NC * a.HsT * a.WsT * 1024;                         // one kind of XkT (bytes)
     char* out = reinterpret_cast<char*>(a.xkt) + ((((long)sb * a.NC + nc) * a.HsT) * a.WsT + cs) * 1024;
     const long rstride = (long)a.WsT * 1024;
+    const bool want_sigma = a.nk > 3;
     auto store4 = [&](int r, uint2 w, uint2 m1, uint2 m2, uint2 sg) {
         char* o = out + (long)r * rstride;
         *reinterpret_cast<uint2*>(o + voff) = w;
         *reinterpret_cast<uint2*>(o + kstride + voff) = m1;
         *reinterpret_cast<uint2*>(o + 2 * kstride + voff) = m2;
-        *reinterpret_cast<uint2*>(o + 3 * kstride + voff) = sg;
+        if (want_sigma) *reinterpret_cast<uint2*>(o + 3 * kstride + voff) = sg;
     };
     const uint2 zero = make_uint2(0u, 0u);
     if (x < 0 || x >= a.W) {                                     // border column
@@ -413,6 +415,7 @@ struct WgGemmArgs {
     const char* et;
     float* c;
     int SB, FB, NC, H, HsT, WsT, WT, nseg, rowf, splits, fgroups;   // WT: columns of a row segment, rowf: its Xk fragments (WT + 8)
+    int nk;                                                         // kinds computed: the first nk of kNumK
     Guard guard;
 };
 
@@ -448,8 +451,8 @@ __global__ void __launch_bounds__(kWWaves * 64) wg_gemm_kernel(const WgGemmArgs 
     const int sb = t % a.SB; t /= a.SB;
     const int fg = t % a.fgroups; t /= a.fgroups;
     const int oy = t % kWD; t /= kWD;
-    const int k = t % kNumK;
-    const int split = t / kNumK;
+    const int k = t % a.nk;
+    const int split = t / a.nk;
     const int per = (a.NC + a.splits - 1) / a.splits;
     const int nc0 = split * per, nc1 = nc0 + per < a.NC ? nc0 + per : a.NC;
     const int fb = fg * kWWaves + wave;
@@ -528,14 +531,16 @@ __global__ void __launch_bounds__(kWWaves * 64) wg_gemm_kernel(const WgGemmArgs 
     }
 }
 
-// r4[k][(s*G+g)*F+f] = sum over the image ranges and the four bilinear taps of the unit.  The loads of four ranges (sixteen values)
-// are issued together; the sums run in double in the fixed order (range, tap), whatever the batching.
+// r4[k][(s*G+g)*F+f] = sum over the image ranges and the four bilinear taps of the unit; one thread per (kind, unit).  The loads of
+// four ranges (sixteen values) are issued together; the sums run in double in the fixed order (range, tap), whatever the batching.
 __global__ void wg_finish_kernel(const float* __restrict__ c, const UnitRef* __restrict__ table, int S, int G, int F, int SP,
-                                 int FP, int splits, float* __restrict__ r4, const Guard guard) {
+                                 int FP, int splits, int nk, float* __restrict__ r4, const Guard guard) {
     if (!guard_pass(guard)) return;
     const long units = (long)S * G * F;
     const size_t plane = (size_t)SP * FP;                    // one displacement
-    for (long u = blockIdx.x * (long)blockDim.x + threadIdx.x; u < units; u += (long)gridDim.x * blockDim.x) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < units * nk; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i / units);
+        const long u = i - (long)k * units;
         const int f = (int)(u % F), s = (int)(u / ((long)F * G));
         const UnitRef ur = table[u];
         int dyi = ur.oy + 4, dxi = ur.ox + 4;
@@ -548,25 +553,23 @@ __global__ void wg_finish_kernel(const float* __restrict__ c, const UnitRef* __r
         const size_t o00 = (size_t)(dyi * kWD + dxi) * plane;
         const size_t off[4] = {o00, xin ? o00 + plane : o00, yin ? o00 + kWD * plane : o00, (xin && yin) ? o00 + (kWD + 1) * plane : o00};
         const float* cu = c + (size_t)s * FP + f;
-        for (int k = 0; k < kNumK; ++k) {
-            double sum = 0.0;
-            for (int sp0 = 0; sp0 < splits; sp0 += 4) {
-                float v[4][4];
+        double sum = 0.0;
+        for (int sp0 = 0; sp0 < splits; sp0 += 4) {
+            float v[4][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int sp = sp0 + q < splits ? sp0 + q : splits - 1;          // (past the end: a valid range, not added)
-                    const float* ck = cu + (((size_t)sp * kNumK + k) * kWD * kWD) * plane;
+            for (int q = 0; q < 4; ++q) {
+                const int sp = sp0 + q < splits ? sp0 + q : splits - 1;          // (past the end: a valid range, not added)
+                const float* ck = cu + (((size_t)sp * kNumK + k) * kWD * kWD) * plane;
 #pragma unroll
-                    for (int tp = 0; tp < 4; ++tp) v[q][tp] = ck[off[tp]];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (sp0 + q < splits)
-#pragma unroll
-                        for (int tp = 0; tp < 4; ++tp) sum += (double)b[tp] * (double)v[q][tp];
+                for (int tp = 0; tp < 4; ++tp) v[q][tp] = ck[off[tp]];
             }
-            r4[(size_t)k * units + u] = (float)sum;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (sp0 + q < splits)
+#pragma unroll
+                    for (int tp = 0; tp < 4; ++tp) sum += (double)b[tp] * (double)v[q][tp];
         }
+        r4[i] = (float)sum;
     }
 }
 
@@ -642,7 +645,8 @@ void dense_wgrad_init(const WgradConfig& c) {
 }
 
 void dense_wgrad_run(hipStream_t st, const WgradConfig& c, const float* x, const float* dy, const float* filters,
-                     const UnitRef* table, int drop_col, int drop_row, float* r4, void* workspace, const Guard& guard) {
+                     const UnitRef* table, int drop_col, int drop_row, float* r4, void* workspace, const Guard& guard, int nk) {
+    nk = nk < 1 ? 1 : (nk > kNumK ? kNumK : nk);
     const WgLayout l = wg_layout(c);
     char* ws = static_cast<char*>(workspace);
     const Shape& s = c.sh;
@@ -668,6 +672,7 @@ void dense_wgrad_run(hipStream_t st, const WgradConfig& c, const float* x, const
         nbands = nbands < 1 ? 1 : (nbands > s.H ? s.H : nbands);
         f.RB = (s.H + nbands - 1) / nbands; f.nbands = (s.H + f.RB - 1) / f.RB;
         f.nblocks = c.SB * c.NC * f.nbands * f.ncolblk;
+        f.nk = nk;
         f.guard = guard;
         void* args[] = {&f};
         (void)hipLaunchKernel(wg_filter_for(c.blur_k), dim3((f.nblocks + 7) / 8 * 8), dim3(256), args, 0, st);
@@ -695,16 +700,16 @@ void dense_wgrad_run(hipStream_t st, const WgradConfig& c, const float* x, const
         WgGemmArgs a{};
         a.xkt = ws + l.xkt_off; a.et = ws + l.et_off; a.c = reinterpret_cast<float*>(ws + l.c_off);
         a.SB = c.SB; a.FB = c.FB; a.NC = c.NC; a.H = s.H; a.HsT = c.HsT; a.WsT = c.WsT; a.WT = c.WT; a.nseg = c.nseg; a.rowf = c.WT + kWD - 1; a.splits = c.splits;
-        a.fgroups = (c.FB + kWWaves - 1) / kWWaves; a.guard = guard;
-        const int grid = c.SB * a.fgroups * kWD * kNumK * c.splits;
+        a.fgroups = (c.FB + kWWaves - 1) / kWWaves; a.nk = nk; a.guard = guard;
+        const int grid = c.SB * a.fgroups * kWD * nk * c.splits;
         void* args[] = {&a};
         (void)hipLaunchKernel(wg_gemm_for(c.WT), dim3(grid), dim3(kWWaves * 64), args, (size_t)2 * (c.WT + kWD - 1) * 1024, st);
     }
     {
-        const long units = (long)s.S * s.G * s.F;
-        const int grid = (int)((units + 255) / 256 < 2048 ? (units + 255) / 256 : 2048);
+        const long units = (long)s.S * s.G * s.F * nk;
+        const int grid = (int)((units + 255) / 256 < 8192 ? (units + 255) / 256 : 8192);
         hipLaunchKernelGGL(wg_finish_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const float*>(ws + l.c_off), table, s.S,
-                           s.G, s.F, c.SB * 32, c.FB * 32, c.splits, r4, guard);
+                           s.G, s.F, c.SB * 32, c.FB * 32, c.splits, nk, r4, guard);
     }
 }
 

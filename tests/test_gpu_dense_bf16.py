@@ -134,6 +134,32 @@ def test_dense_forms_under_other_prefilter_supports(shape, sigma):
         assert_parity(t.cpu().numpy(), want[key], "%s sigma %g" % (key, sigma), rel=2e-2, floor=1e-2)
 
 
+def test_dense_parameter_gradients_without_the_sigma_kind():
+    """A call that does not want dsigma (the layer's default: dau_sigma_trainable=False; the reference's last_k_optional,
+    dau_conv_backward.cpp:219) runs three of the four kinds of GEMMs: dw, dmu1, dmu2 are bit-identical to the call that wants
+    all five, dsigma is not produced, and the next full call is unaffected."""
+    from dau_conv import _capi
+    N, S, F, G, H, W = 18, 33, 40, 4, 30, 45
+    xb, dyb, w, mu1, mu2 = _case(59, N, S, F, G, H, W, 3.99)
+    flags = _capi.FLAG_USE_INTERPOLATION | _capi.FLAG_IO_BF16 | _capi.FLAG_DENSE_BF16
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=flags)
+    assert plan.info["gather_dense_bf16"] == 2
+    dev = lambda a: torch.from_numpy(a).cuda()
+    sigma = torch.full((1, S, G, F), 0.5, device="cuda")
+    args = (xb.cuda(), dyb.cuda(), dev(w), dev(mu1), dev(mu2), sigma)
+    full = plan.backward(*args)
+    part = plan.backward(*args, need_mask=_capi.NEED_ALL & ~_capi.NEED_DSIGMA)
+    again = plan.backward(*args)
+    plan.check_status()
+    assert part[4] is None
+    for a, b, c, key in zip(full[:4], part[:4], again[:4], ("dx", "dw", "dmu1", "dmu2")):
+        assert torch.equal(a, b) and torch.equal(a, c), key
+    assert torch.equal(full[4], again[4])
+    want = orc.backward(xb.float().numpy(), dyb.float().numpy(), w, mu1, mu2, 0.5)
+    for t, key in zip(part[1:4], ("dw", "dmu1", "dmu2")):
+        assert_parity(t.cpu().numpy(), want[key], key, rel=2e-2, floor=4e-3)
+
+
 def test_dense_bf16_under_a_larger_kernel_follows_the_offsets():
     """max_kernel_size 17 with the dense flag: calls with |mu| <= 4 take the dense GEMM (after the first call has left its
     hint), calls with larger offsets the exact gather of bucket 8; both match the oracle."""

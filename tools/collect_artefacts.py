@@ -12,7 +12,7 @@ with open('profiles/r3_bench_configs.jsonl','w') as fh:
     for t in ['fa_bench_c1','fa_bench_c2','fa_bench_c2f32','fa_bench_c3','fa_bench_c4','fa_bench_c4grid','fa_bench_c4k33','fa_bench_nsk65','fa_bench_k17']:
         fh.write(last_json_line(G+'%s.log'%t)+'\n')
 with open('profiles/r3_bench_dense_bf16.jsonl','w') as fh:
-    for t in ['fa_bench_c2dense','fa_bench_nsdense']:
+    for t in ['fa_bench_c2dense','fa_bench_nsdense','fa_bench_c2dense_nosigma']:
         fh.write(last_json_line(G+'%s.log'%t)+'\n')
 open('profiles/r3_bench_gloo2_rehearsal.json','w').write(last_json_line(G+'fa_gloo2.log')+'\n')
 open('profiles/r3_bench_dist1_rccl.json','w').write(last_json_line(G+'fa_dist1.log')+'\n')
@@ -36,7 +36,7 @@ out={"_comment":"rocprofv3 --pmc (three passes, no trace domains) of `python3 be
   "waves_resident_per_simd (SQ_WAVE_CYCLES counts quad cycles)":4*c["SQ_WAVE_CYCLES"]/(cyc*1024),
   "lane_utilisation (MFMAs needed per pass if every lane had a unit / MFMAs issued per pass)":need_pass/(ndisp*c['SQ_INSTS_MFMA'])}}
 json.dump(out,open('profiles/r3_pmc_sq_counters_c4.json','w'),indent=1)
-for t in ['fa_bench_ns','fa_bench_ns400','fa_bench_c1','fa_bench_c2','fa_bench_c2dense','fa_bench_c2f32','fa_bench_c3','fa_bench_c4','fa_bench_c4grid','fa_bench_c4k33','fa_bench_nsk65','fa_bench_nsdense','fa_bench_k17','fa_gloo2','fa_dist1']:
+for t in ['fa_bench_ns','fa_bench_ns400','fa_bench_c1','fa_bench_c2','fa_bench_c2dense','fa_bench_c2f32','fa_bench_c3','fa_bench_c4','fa_bench_c4grid','fa_bench_c4k33','fa_bench_nsk65','fa_bench_nsdense','fa_bench_c2dense_nosigma','fa_bench_k17','fa_gloo2','fa_dist1']:
     d=json.loads(last_json_line(G+'%s.log'%t)); r=d.get('roofline') or {}
     print(t, d['ms_per_step'], 'steady',r.get('steady_state_ms'), 'TF',r.get('whole_step_tflops'), {n:(v['avg_ms'],v['tflops']) for n,v in r.get('kernels',{}).items()}, 'parity',(d.get('parity_gate') or {}).get('ok'), 'layer',(d.get('layer') or {}).get('ms_per_step'), 'traffic', r.get('traffic'), d['lib'])
 print(json.dumps(out['derived'],indent=1))
