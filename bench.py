@@ -402,7 +402,9 @@ def main():
         if (dense_level >= 1 and dominant != "gather_dot") or (dense_level == 2 and dominant == "gather_dot"):
             # the pass ran in its densified form on the bf16 matrix cores: price the FLOPs that form executes (9 x 9 = 81 taps per
             # (input, output) channel pair and pixel; 324 for the four parameter-gradient kinds) against the bf16 roof
-            taps = (243.0 if args.no_dsigma else 324.0) if dominant == "gather_dot" else 81.0
+            # (offsets within +-3, as every BASELINE workload draws them, take the radius-3 members: 7 x 7 taps / displacements)
+            side = 7.0 if float(m) <= 3.0 else 9.0
+            taps = side * side * ((3.0 if args.no_dsigma else 4.0) if dominant == "gather_dot" else 1.0)
             ach = 2.0 * taps * N * H * W * S * F / (kern[dominant]["avg_ms"] * 1e-3) / 1e12
             peak = BF16_PEAK_TFLOPS
             roof_note = ("densified bf16 form: achieved = executed dense FLOPs (2*%d*N*H*W*S*F) / time against the dense bf16 "

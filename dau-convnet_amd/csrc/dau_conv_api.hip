@@ -90,6 +90,11 @@ struct BucketSet {
     bool wgrad_ok = false;
     WgradConfig wgrad;
     DenseConfig dense_fwd, dense_dx;
+    // ... and the same two forms for calls whose offsets lie within +-3 (7 x 7 taps / displacements instead of 9 x 9; the call's
+    // device guard decides between the two: (-1, 3] and (3, 4])
+    bool dense3_ok = false, wgrad3_ok = false;
+    DenseConfig dense3_fwd, dense3_dx;
+    WgradConfig wgrad3;
     // Batch slabs.  Every pass stages its whole input before it gathers; where that staged copy would exceed the workspace
     // budget (DAU_WORKSPACE_BUDGET_GB at plan creation, default 12: only the 512 x 512 configurations get there) the pass
     // runs slab by slab over the batch -- the configs above are made for `slab_*` images, the passes loop -- so that the
@@ -161,6 +166,7 @@ struct ProfScope {
 struct Candidate {
     const BucketSet* set;
     Guard guard;
+    bool r3 = false;          // the set's radius-3 dense member (sets[0] only)
 };
 
 void clear_host_status(const dau_conv_plan* p) {
@@ -172,14 +178,18 @@ void clear_host_status(const dau_conv_plan* p) {
 // pass_kind: 0 = gather-sum (needs fwd_ok), 1 = gather-dot (needs dot_ok)
 // A plan with DAU_FLAG_DENSE_BF16 has one member whose ARITHMETIC differs (bucket 4: bf16 products): that member is enqueued,
 // guarded by (-1, 4], on every call, hint or no hint, so that which arithmetic a call gets depends on its own offsets only.
-constexpr int kMaxCandidates = 3;
+// The dense forms exist for |mu| <= 3 as well (49 taps instead of 81): that member goes first, guarded by (-1, 3].
+constexpr int kMaxCandidates = 4;
 int pick_candidates(const dau_conv_plan* p, const Status* dev_status, int pass_kind, Candidate out[kMaxCandidates]) {
     const BucketSet* top = &p->top();
     out[0] = Candidate{top, Guard{nullptr, 0.0f, 0.0f}};
-    if (!p->dynamic || p->nsets < 2) return 1;
-    const BucketSet* dense = (pass_kind == 0 ? p->sets[0].dense_ok : p->sets[0].wgrad_ok) ? &p->sets[0] : nullptr;
+    if (!p->dynamic) return 1;
+    const BucketSet& s0 = p->sets[0];
+    const bool d3 = pass_kind == 0 ? s0.dense3_ok : s0.wgrad3_ok;
+    if (p->nsets < 2 && !d3) return 1;
+    const BucketSet* dense = (pass_kind == 0 ? s0.dense_ok : s0.wgrad_ok) ? &s0 : nullptr;
     const BucketSet* hinted = nullptr;
-    if (p->host_status) {
+    if (p->host_status && p->nsets >= 2) {
         const volatile unsigned* h = reinterpret_cast<const volatile unsigned*>(p->host_status);
         float mx = -1.0f;
         if (h[2] == 1u && h[1] == 0u) {
@@ -194,7 +204,8 @@ int pick_candidates(const dau_conv_plan* p, const Status* dev_status, int pass_k
     }
     int n = 0;
     float lo = -1.0f;
-    if (dense && hinted != dense) { out[n++] = Candidate{dense, Guard{dev_status, lo, (float)dense->bucket}}; lo = (float)dense->bucket; }
+    if (d3) { out[n] = Candidate{&s0, Guard{dev_status, lo, 3.0f}}; out[n++].r3 = true; lo = 3.0f; }
+    if (dense && hinted != dense && dense != top) { out[n++] = Candidate{dense, Guard{dev_status, lo, (float)dense->bucket}}; lo = (float)dense->bucket; }
     if (hinted) { out[n++] = Candidate{hinted, Guard{dev_status, lo, (float)hinted->bucket}}; lo = (float)hinted->bucket; }
     if (n == 0) return 1;                                    // no hint, nothing dense: the static set, unguarded
     out[n++] = Candidate{top, Guard{dev_status, lo, INFINITY}};
@@ -215,8 +226,10 @@ int ensure_attrs(const dau_conv_plan* p) {
     for (int i = 0; i < p->nsets; ++i) {
         if (p->sets[i].fwd_ok) { tiled_gather_init(p->sets[i].tiled_fwd); tiled_gather_init(p->sets[i].tiled_dx); }
         if (p->sets[i].dot_ok) tiled_dot_init(p->sets[i].tiled_dot);
-        if (p->sets[i].dense_ok) { dense_gather_init(p->sets[i].dense_fwd); dense_gather_init(p->sets[i].dense_dx); }
-        if (p->sets[i].wgrad_ok) dense_wgrad_init(p->sets[i].wgrad);
+        if (p->sets[i].dense_ok) { r4::dense_gather_init(p->sets[i].dense_fwd); r4::dense_gather_init(p->sets[i].dense_dx); }
+        if (p->sets[i].wgrad_ok) r4::dense_wgrad_init(p->sets[i].wgrad);
+        if (p->sets[i].dense3_ok) { r3::dense_gather_init(p->sets[i].dense3_fwd); r3::dense_gather_init(p->sets[i].dense3_dx); }
+        if (p->sets[i].wgrad3_ok) r3::dense_wgrad_init(p->sets[i].wgrad3);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return fail(DAU_INTERNAL, "raising the dynamic-LDS limit of the bucket-%d kernels failed: %s", p->sets[i].bucket,
@@ -245,7 +258,8 @@ FwdWs carve_forward(const dau_conv_plan* p, void* ws) {
         size_t need = 0;
         for (int i = 0; i < p->nsets; ++i) {
             if (p->sets[i].fwd_ok) need = std::max(need, tiled_gather_workspace_bytes(p->sets[i].tiled_fwd));
-            if (p->sets[i].dense_ok) need = std::max(need, dense_gather_workspace_bytes(p->sets[i].dense_fwd));
+            if (p->sets[i].dense_ok) need = std::max(need, r4::dense_gather_workspace_bytes(p->sets[i].dense_fwd));
+            if (p->sets[i].dense3_ok) need = std::max(need, r3::dense_gather_workspace_bytes(p->sets[i].dense3_fwd));
         }
         w.tiled = c.take<char>(need);
     } else {
@@ -281,8 +295,10 @@ BwdWs carve_backward(const dau_conv_plan* p, void* ws) {
         size_t need = 0;
         for (int i = 0; i < p->nsets; ++i)
             if (p->sets[i].dot_ok) need = std::max(need, tiled_dot_workspace_bytes(p->sets[i].tiled_dot));
-        for (int i = 0; i < p->nsets; ++i)
-            if (p->sets[i].wgrad_ok) need = std::max(need, dense_wgrad_workspace_bytes(p->sets[i].wgrad));
+        for (int i = 0; i < p->nsets; ++i) {
+            if (p->sets[i].wgrad_ok) need = std::max(need, r4::dense_wgrad_workspace_bytes(p->sets[i].wgrad));
+            if (p->sets[i].wgrad3_ok) need = std::max(need, r3::dense_wgrad_workspace_bytes(p->sets[i].wgrad3));
+        }
         w.tiled_dot = c.take<char>(need);
     } else {
         w.xk4 = c.take<float>((size_t)kNumK * s.N * s.S * s.H * s.W);
@@ -291,7 +307,8 @@ BwdWs carve_backward(const dau_conv_plan* p, void* ws) {
         size_t need = 0;
         for (int i = 0; i < p->nsets; ++i) {
             if (p->sets[i].fwd_ok) need = std::max(need, tiled_gather_workspace_bytes(p->sets[i].tiled_dx));
-            if (p->sets[i].dense_ok) need = std::max(need, dense_gather_workspace_bytes(p->sets[i].dense_dx));
+            if (p->sets[i].dense_ok) need = std::max(need, r4::dense_gather_workspace_bytes(p->sets[i].dense_dx));
+            if (p->sets[i].dense3_ok) need = std::max(need, r3::dense_gather_workspace_bytes(p->sets[i].dense3_dx));
         }
         w.tiled_dx = c.take<char>(need);
     } else {
@@ -372,11 +389,15 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
             bs.fwd_ok = tiled_gather_configure(n, s.S, s.F, s.G, s.H, s.W, b, blur_k, bf16, &bs.tiled_fwd) &&
                         tiled_gather_configure(n, s.F, s.S, s.G, s.H, s.W, b, blur_k, bf16, &bs.tiled_dx);
             bs.dense_ok = want_dense && bs.fwd_ok &&
-                          dense_gather_configure(n, s.S, s.F, s.G, s.H, s.W, b, blur_k, bf16, &bs.dense_fwd) &&
-                          dense_gather_configure(n, s.F, s.S, s.G, s.H, s.W, b, blur_k, bf16, &bs.dense_dx);
+                          r4::dense_gather_configure(n, s.S, s.F, s.G, s.H, s.W, b, blur_k, bf16, &bs.dense_fwd) &&
+                          r4::dense_gather_configure(n, s.F, s.S, s.G, s.H, s.W, b, blur_k, bf16, &bs.dense_dx);
+            bs.dense3_ok = bs.dense_ok && b == 4 && DAU_TUNE_INT("DAU_DENSE_R3", 1) != 0 &&
+                           r3::dense_gather_configure(n, s.S, s.F, s.G, s.H, s.W, 3, blur_k, bf16, &bs.dense3_fwd) &&
+                           r3::dense_gather_configure(n, s.F, s.S, s.G, s.H, s.W, 3, blur_k, bf16, &bs.dense3_dx);
             size_t need = 0;
             if (bs.fwd_ok) need = std::max(tiled_gather_workspace_bytes(bs.tiled_fwd), tiled_gather_workspace_bytes(bs.tiled_dx));
-            if (bs.dense_ok) need = std::max(need, std::max(dense_gather_workspace_bytes(bs.dense_fwd), dense_gather_workspace_bytes(bs.dense_dx)));
+            if (bs.dense_ok) need = std::max(need, std::max(r4::dense_gather_workspace_bytes(bs.dense_fwd), r4::dense_gather_workspace_bytes(bs.dense_dx)));
+            if (bs.dense3_ok) need = std::max(need, std::max(r3::dense_gather_workspace_bytes(bs.dense3_fwd), r3::dense_gather_workspace_bytes(bs.dense3_dx)));
             return need;
         };
         auto configure_dot = [&](int n) {
@@ -402,8 +423,10 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
             // four-unit block, 9.7 ms of two units); DAU_FLAG_DENSE_WGRAD_NEVER / _ALWAYS: never / from one unit on
             const int min_units = (desc->flags & DAU_FLAG_DENSE_WGRAD_NEVER) ? 1 << 30 : (desc->flags & DAU_FLAG_DENSE_WGRAD_ALWAYS) ? 1 : 3;
             bs.wgrad_ok = want_dense && bf16 && b == 4 && bs.dense_ok && bs.dot_ok && bs.slab_dot == s.N && s.G >= min_units &&
-                          dense_wgrad_configure(s, blur_k, bf16, &bs.wgrad) &&
-                          (double)dense_wgrad_workspace_bytes(bs.wgrad) <= budget_bytes;
+                          r4::dense_wgrad_configure(s, blur_k, bf16, &bs.wgrad) &&
+                          (double)r4::dense_wgrad_workspace_bytes(bs.wgrad) <= budget_bytes;
+            bs.wgrad3_ok = bs.wgrad_ok && bs.dense3_ok && r3::dense_wgrad_configure(s, blur_k, bf16, &bs.wgrad3) &&
+                           (double)r3::dense_wgrad_workspace_bytes(bs.wgrad3) <= budget_bytes;
         }
     }
     if ((desc->flags & DAU_FLAG_DENSE_BF16) && !bf16) {
@@ -426,10 +449,10 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
     }
     p->algo_fwd = (desc->algo != DAU_ALGO_DIRECT && fwd_ok) ? DAU_ALGO_TILED : DAU_ALGO_DIRECT;
     p->algo_bwd = (desc->algo != DAU_ALGO_DIRECT && dot_ok) ? DAU_ALGO_TILED : DAU_ALGO_DIRECT;
-    // dynamic bucket selection: tiled kernels, more than one bucket, not switched off (DAU_FLAG_STATIC_BUCKET; tuning build:
+    // dynamic bucket selection: tiled kernels, more than one bucket (or the two radii of the dense forms), not switched off (DAU_FLAG_STATIC_BUCKET; tuning build:
     // DAU_DYNAMIC_BUCKET=0 in the environment at plan creation).  The pinned status mirror needs a device; without one
     // (header-only checks on a CPU box) the plan simply has no hint.
-    p->dynamic = p->nsets > 1 && !(desc->flags & DAU_FLAG_STATIC_BUCKET) && DAU_TUNE_INT("DAU_DYNAMIC_BUCKET", 1) != 0 &&
+    p->dynamic = (p->nsets > 1 || p->sets[0].dense3_ok) && !(desc->flags & DAU_FLAG_STATIC_BUCKET) && DAU_TUNE_INT("DAU_DYNAMIC_BUCKET", 1) != 0 &&
                  (p->algo_fwd == DAU_ALGO_TILED || p->algo_bwd == DAU_ALGO_TILED);
     void* hs = nullptr;
     if (hipHostMalloc(&hs, sizeof(HostStatus), hipHostMallocDefault) == hipSuccess && hs) {
@@ -535,10 +558,16 @@ int dau_conv_forward(const dau_conv_plan* p, void* stream, const float* x, const
             for (int n0 = 0; n0 < s.N; n0 += bs.slab_gather) {             // one slab unless the staged copy exceeds the budget
                 const float* xs = slab_ptr(x, (size_t)n0 * s.S * s.H * s.W, esize);
                 float* ys = slab_ptr(y, (size_t)n0 * s.F * s.H * s.W, esize);
-                if (bs.dense_ok) {                                         // bf16 layer, offsets within +-4: dense implicit GEMM
-                    dense_gather_prepare(st, bs.dense_fwd, xs, ws.filters, false, ws.table, ws.tiled, cand[ci].guard);
+                if (cand[ci].r3) {                                         // bf16 layer, offsets within +-3: 7 x 7 dense kernel
+                    r3::dense_gather_prepare(st, bs.dense3_fwd, xs, ws.filters, false, ws.table, ws.tiled, cand[ci].guard);
                     ProfScope prof(p, 0, st);
-                    dense_gather_run(st, bs.dense_fwd, ys, ws.tiled, cand[ci].guard);
+                    r3::dense_gather_run(st, bs.dense3_fwd, ys, ws.tiled, cand[ci].guard);
+                    continue;
+                }
+                if (bs.dense_ok) {                                         // bf16 layer, offsets within +-4: dense implicit GEMM
+                    r4::dense_gather_prepare(st, bs.dense_fwd, xs, ws.filters, false, ws.table, ws.tiled, cand[ci].guard);
+                    ProfScope prof(p, 0, st);
+                    r4::dense_gather_run(st, bs.dense_fwd, ys, ws.tiled, cand[ci].guard);
                     continue;
                 }
                 const TiledConfig& cfg = bs.tiled_fwd;
@@ -577,9 +606,14 @@ int run_param_sums(const dau_conv_plan* p, hipStream_t st, const float* x, const
         for (int ci = 0; ci < ncand; ++ci) {
             const BucketSet& bs = *cand[ci].set;
             const TiledDotConfig& cfg = bs.tiled_dot;
+            if (cand[ci].r3) {                                                 // offsets within +-3: 49 displacements
+                ProfScope prof(p, 2, st);
+                r3::dense_wgrad_run(st, bs.wgrad3, x, dy, ws.filters, ws.table_bare, p->drop_col, p->drop_row, r4, ws.tiled_dot, cand[ci].guard, kinds);
+                continue;
+            }
             if (bs.wgrad_ok) {                                                 // bf16 layer, offsets within +-4, many units
                 ProfScope prof(p, 2, st);
-                dense_wgrad_run(st, bs.wgrad, x, dy, ws.filters, ws.table_bare, p->drop_col, p->drop_row, r4, ws.tiled_dot, cand[ci].guard, kinds);
+                r4::dense_wgrad_run(st, bs.wgrad, x, dy, ws.filters, ws.table_bare, p->drop_col, p->drop_row, r4, ws.tiled_dot, cand[ci].guard, kinds);
                 continue;
             }
             for (int n0 = 0; n0 < s.N; n0 += bs.slab_dot) {                // the sums of the slabs add up in r4
@@ -646,10 +680,16 @@ int dau_conv_backward(const dau_conv_plan* p, void* stream, const float* x, cons
                 for (int n0 = 0; n0 < s.N; n0 += bs.slab_gather) {
                     const float* dys = slab_ptr(dy, (size_t)n0 * s.F * s.H * s.W, esize);
                     float* dxs = slab_ptr(dx, (size_t)n0 * s.S * s.H * s.W, esize);
-                    if (bs.dense_ok) {
-                        dense_gather_prepare(st, bs.dense_dx, dys, ws.filters, true, ws.table_t, ws.tiled_dx, cand[ci].guard);
+                    if (cand[ci].r3) {
+                        r3::dense_gather_prepare(st, bs.dense3_dx, dys, ws.filters, true, ws.table_t, ws.tiled_dx, cand[ci].guard);
                         ProfScope prof(p, 1, st);
-                        dense_gather_run(st, bs.dense_dx, dxs, ws.tiled_dx, cand[ci].guard);
+                        r3::dense_gather_run(st, bs.dense3_dx, dxs, ws.tiled_dx, cand[ci].guard);
+                        continue;
+                    }
+                    if (bs.dense_ok) {
+                        r4::dense_gather_prepare(st, bs.dense_dx, dys, ws.filters, true, ws.table_t, ws.tiled_dx, cand[ci].guard);
+                        ProfScope prof(p, 1, st);
+                        r4::dense_gather_run(st, bs.dense_dx, dxs, ws.tiled_dx, cand[ci].guard);
                         continue;
                     }
                     const TiledConfig& cfg = bs.tiled_dx;

@@ -49,13 +49,20 @@ struct DenseConfig {
     int nsub;         // 8-pixel subtiles per column block = kernel instantiation
     int ftiles;       // 32-channel accumulator tiles per wave (2: four waves per workgroup, 1: eight)
 };
-bool dense_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, bool bf16, DenseConfig* cfg);
-size_t dense_gather_workspace_bytes(const DenseConfig& cfg);
-void dense_gather_init(const DenseConfig& cfg);
-// prepare: dense kernel synthesis from the unit table ([Cin][G][Cout]) + blurred bf16 staging of `in`; run: the GEMM
-void dense_gather_prepare(hipStream_t st, const DenseConfig& cfg, const float* in, const float* filters, bool mirrored,
-                          const UnitRef* table, void* workspace, const Guard& guard);
-void dense_gather_run(hipStream_t st, const DenseConfig& cfg, float* out, void* workspace, const Guard& guard);
+// The functions exist once per offset radius of the dense form, in the namespaces r4 (|mu| <= 4: 9 x 9 taps) and r3 (|mu| <= 3:
+// 7 x 7): the same source compiled twice (Makefile); `R` of configure must be the namespace's radius.
+#define DAU_DECLARE_DENSE_GATHER(NS)                                                                                           \
+    namespace NS {                                                                                                            \
+    bool dense_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, bool bf16, DenseConfig* cfg); \
+    size_t dense_gather_workspace_bytes(const DenseConfig& cfg);                                                              \
+    void dense_gather_init(const DenseConfig& cfg);                                                                           \
+    /* prepare: dense kernel synthesis from the unit table ([Cin][G][Cout]) + blurred bf16 staging of `in`; run: the GEMM */  \
+    void dense_gather_prepare(hipStream_t st, const DenseConfig& cfg, const float* in, const float* filters, bool mirrored,   \
+                              const UnitRef* table, void* workspace, const Guard& guard);                                     \
+    void dense_gather_run(hipStream_t st, const DenseConfig& cfg, float* out, void* workspace, const Guard& guard);           \
+    }
+DAU_DECLARE_DENSE_GATHER(r4)
+DAU_DECLARE_DENSE_GATHER(r3)
 
 struct TiledDotConfig {
     Shape sh;
@@ -104,13 +111,19 @@ struct WgradConfig {
     bool fused;           // XkT is written from x through the transposed bf16 copy (instantiated prefilter supports); else
                           // through the fp32 copy of blur4_pack
 };
-bool dense_wgrad_configure(const Shape& sh, int blur_k, bool bf16, WgradConfig* cfg);
-size_t dense_wgrad_workspace_bytes(const WgradConfig& cfg);
-void dense_wgrad_init(const WgradConfig& cfg);
+// (once per radius, as the dense gather-sum: namespaces r4 and r3)
 // r4[k][s][g][f] = raw parameter-gradient sums; x, dy bfloat16 NCHW; table = bare unit table [S][G][F].  nk: kinds computed (w, mu1,
 // mu2, sigma in this order): 3 leaves the sigma block of r4 untouched (a caller that does not want dsigma; the reference's
 // last_k_optional: base_dau_conv_layer.hpp:213, src/dau_conv/dau_conv_impl/dau_conv_backward.cpp:219)
-void dense_wgrad_run(hipStream_t st, const WgradConfig& cfg, const float* x, const float* dy, const float* filters,
-                     const UnitRef* table, int drop_col, int drop_row, float* r4, void* workspace, const Guard& guard, int nk);
+#define DAU_DECLARE_DENSE_WGRAD(NS)                                                                                            \
+    namespace NS {                                                                                                            \
+    bool dense_wgrad_configure(const Shape& sh, int blur_k, bool bf16, WgradConfig* cfg);                                     \
+    size_t dense_wgrad_workspace_bytes(const WgradConfig& cfg);                                                               \
+    void dense_wgrad_init(const WgradConfig& cfg);                                                                            \
+    void dense_wgrad_run(hipStream_t st, const WgradConfig& cfg, const float* x, const float* dy, const float* filters,       \
+                         const UnitRef* table, int drop_col, int drop_row, float* r4, void* workspace, const Guard& guard, int nk); \
+    }
+DAU_DECLARE_DENSE_WGRAD(r4)
+DAU_DECLARE_DENSE_WGRAD(r3)
 
 }  // namespace dau

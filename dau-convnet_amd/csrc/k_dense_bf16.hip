@@ -31,7 +31,17 @@
 
 #include "dau_tiled.hpp"
 
+// The file is compiled once per offset radius of the dense form (Makefile): R = 4 (namespace r4, the bucket-4 member: |mu| <= 4)
+// and R = 3 (namespace r3: calls whose |mu| <= 3 -- 49 taps instead of 81; the device guard of the call picks one of the two).
+#ifndef DAU_DENSE_R
+#define DAU_DENSE_R 4                   // (tools/build_variant.sh ... -DDAU_DENSE_R=8: the 18 x 18 form of bucket 8, timing experiment, DESIGN 5.5)
+#endif
+#ifndef DAU_DENSE_NS
+#define DAU_DENSE_NS r4
+#endif
+
 namespace dau {
+namespace DAU_DENSE_NS {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -39,14 +49,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 namespace {
 
-#ifndef DAU_DENSE_R
-#define DAU_DENSE_R 4                   // (tools/build_variant.sh ... -DDAU_DENSE_R=8: the 18 x 18 form of bucket 8, timing experiment, DESIGN 5.5)
-#endif
 constexpr int kDR = DAU_DENSE_R;        // offset radius of the dense form
 // Taps per axis: integer offsets -R .. R plus the second bilinear tap.  An offset of exactly +R has fraction 0, so the taps at
 // R + 1 carry the weight 0 for every unit a guarded call can see (|mu| <= R): the production form (R = 4) leaves that row and
 // column out -- 81 taps instead of 100.  (The R = 8 timing variant keeps the 18 x 18 form it was measured with.)
-constexpr int kDK = kDR == 4 ? 2 * kDR + 1 : 2 * kDR + 2;
+constexpr int kDK = kDR <= 4 ? 2 * kDR + 1 : 2 * kDR + 2;
 constexpr int kDSpan = kDK - 1;         // border of the staged plane and of the LDS window (positions)
 constexpr int kDTaps = kDK * kDK;
 constexpr int kDRows = 8;               // output rows per workgroup
@@ -464,7 +471,7 @@ __global__ void __launch_bounds__(FT == 2 ? 256 : 512) dense_gather_kernel(const
 #ifndef DAU_DENSE_RING9
 #define DAU_DENSE_RING9 1
 #endif
-    constexpr int kRing = kDK % 5 == 0 ? 5 : kDK % 6 == 0 ? 6 : (DAU_DENSE_RING9 && NSUB * FT <= 7 ? 9 : 3);
+    constexpr int kRing = kDK % 5 == 0 ? 5 : kDK % 6 == 0 ? 6 : kDK == 7 ? 7 : (DAU_DENSE_RING9 && NSUB * FT <= 7 ? 9 : 3);
     static_assert(kDK % kRing == 0, "A ring");
     bf16x8 af[kRing][FT];
     const bf16x8* wp = wsrc;                                  // tap 0 of chunk 0
@@ -693,4 +700,5 @@ void dense_gather_run(hipStream_t st, const DenseConfig& c, float* out, void* wo
     dispatch_dense(c.nsub, c.ftiles, st, &a, grid);
 }
 
+}  // namespace DAU_DENSE_NS
 }  // namespace dau

@@ -31,7 +31,15 @@
 
 #include "dau_tiled.hpp"
 
+#ifndef DAU_DENSE_R
+#define DAU_DENSE_R 4          // compiled once per radius, as k_dense_bf16.hip: namespaces r4 (|mu| <= 4) and r3 (|mu| <= 3: 49 displacements)
+#endif
+#ifndef DAU_DENSE_NS
+#define DAU_DENSE_NS r4
+#endif
+
 namespace dau {
+namespace DAU_DENSE_NS {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -40,7 +48,8 @@ typedef __attribute__((address_space(1))) const void* glb_ptr_t;
 
 namespace {
 
-constexpr int kWD = 9;             // displacements per axis: -4 .. 4 (the tap at +5 belongs to an offset of exactly +4: fraction 0,
+constexpr int kWR = DAU_DENSE_R;   // offset radius
+constexpr int kWD = 2 * kWR + 1;   // displacements per axis: -R .. R (the tap at R + 1 belongs to an offset of exactly +R: fraction 0,
                                    // weight 0 -- wg_finish_kernel never reads it)
 constexpr int kWMaxSteps = 60;     // widest row (columns per row are straight-line code: see wg_gemm_kernel)
 constexpr int kWAhead = 5;         // E' fragments in flight ahead of the one in use
@@ -83,7 +92,7 @@ __global__ void __launch_bounds__(512) wg_stage_x_kernel(const WgStageXArgs a) {
     const int yy = t % a.HsT; t /= a.HsT;
     const int nc = t % a.NC;
     const int sb = t / a.NC;
-    const int y = yy - 4, x0 = xr * 8 - 4;                 // image coordinates of the run
+    const int y = yy - kWR, x0 = xr * 8 - kWR;             // image coordinates of the run
     const bool row_in = y >= 0 && y < a.H;
     // load: 256 (pair, channel) rows of 64 floats; a thread takes float4 pieces (16 per row)
     for (int i = threadIdx.x; i < 256 * 16; i += blockDim.x) {
@@ -220,9 +229,9 @@ __global__ void __launch_bounds__(256) wg_filter_kernel(const WgFilterArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // everything below but `voff` is wave-uniform: scalar registers
     const int half = wave & 1, cs = cb * 2 + (wave >> 1);        // staged column; image column x = cs - 4
     if (cs >= a.WsT) return;
-    const int x = cs - 4;
+    const int x = cs - kWR;
     const int y0 = band * a.RB, y1 = y0 + a.RB < a.H ? y0 + a.RB : a.H;
-    const int rs0 = band == 0 ? 0 : y0 + 4, rs1 = band == a.nbands - 1 ? a.HsT : y1 + 4;   // staged rows this wave writes
+    const int rs0 = band == 0 ? 0 : y0 + kWR, rs1 = band == a.nbands - 1 ? a.HsT : y1 + kWR;   // staged rows this wave writes
     const unsigned voff = (unsigned)(half * 512 + lane * 8);     // this lane's 8 bytes of a fragment
     const long kstride = (long)a.SB * a.NC * a.HsT * a.WsT * 1024;                         // one kind of XkT (bytes)
     char* out = reinterpret_cast<char*>(a.xkt) + ((((long)sb * a.NC + nc) * a.HsT) * a.WsT + cs) * 1024;
@@ -240,8 +249,8 @@ __global__ void __launch_bounds__(256) wg_filter_kernel(const WgFilterArgs a) {
         for (int r = rs0; r < rs1; ++r) store4(r, zero, zero, zero, zero);
         return;
     }
-    for (int r = rs0; r < y0 + 4; ++r) store4(r, zero, zero, zero, zero);
-    for (int r = y1 + 4; r < rs1; ++r) store4(r, zero, zero, zero, zero);
+    for (int r = rs0; r < y0 + kWR; ++r) store4(r, zero, zero, zero, zero);
+    for (int r = y1 + kWR; r < rs1; ++r) store4(r, zero, zero, zero, zero);
     float gxt[K], axt[K], cxt[K], gyt[K], ayt[K], byt[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) {
@@ -330,7 +339,7 @@ __global__ void __launch_bounds__(256) wg_filter_kernel(const WgFilterArgs a) {
                 }
             }
             if (o0 + j < nout)
-                store4(y0 + o0 + j + 4, make_uint2(pack_bf16x2(dw[0], dw[1]), pack_bf16x2(dw[2], dw[3])),
+                store4(y0 + o0 + j + kWR, make_uint2(pack_bf16x2(dw[0], dw[1]), pack_bf16x2(dw[2], dw[3])),
                        make_uint2(pack_bf16x2(d1[0], d1[1]), pack_bf16x2(d1[2], d1[3])),
                        make_uint2(pack_bf16x2(d2[0], d2[1]), pack_bf16x2(d2[2], d2[3])),
                        make_uint2(pack_bf16x2(ds[0], ds[1]), pack_bf16x2(ds[2], ds[3])));
@@ -507,8 +516,20 @@ __global__ void __launch_bounds__(kWWaves * 64) wg_gemm_kernel(const WgGemmArgs 
         for (int x = 0; x < NSTEP; ++x) {
             // the window holds staged columns x .. x+8 (slot = column mod 9), eq[x mod 6] = E'(x)
             win[(x + kWD - 1) % kWD] = *reinterpret_cast<const bf16x8*>(arow + (x + kWD - 1) * 1024);
-            WG_ELOAD(eq[(x + kWAhead) % kWSlots], lfrag, erow + (x + kWAhead) * 1024);     // (the buffer has slack past its end)
-            if (x < kWAhead) wg_vmwait<kWAhead + kWDma>(); else wg_vmwait<kWAhead>();
+            // No look-ahead past the row's end: a register that receives a load nobody will read is free for hipcc to give to
+            // something else right after the asm statement -- and the data that lands in it later corrupts that (seen with seven
+            // accumulators: the E' fragments of the next row's first columns ended up in the Xk window).  The counted waits follow
+            // the loads that are really in flight behind E'(x).
+            if (x + kWAhead < NSTEP) WG_ELOAD(eq[(x + kWAhead) % kWSlots], lfrag, erow + (x + kWAhead) * 1024);
+            const int behind = NSTEP - 1 - x;                 // E' loads of this row issued after E'(x) (x is a constant once unrolled)
+            static_assert(kWAhead == 5, "the tail below counts down from four");
+            if (x < kWAhead) wg_vmwait<kWAhead + kWDma>();
+            else if (behind >= kWAhead) wg_vmwait<kWAhead>();
+            else if (behind == 4) wg_vmwait<4>();
+            else if (behind == 3) wg_vmwait<3>();
+            else if (behind == 2) wg_vmwait<2>();
+            else if (behind == 1) wg_vmwait<1>();
+            else wg_vmwait<0>();
             const bf16x8 e = __builtin_bit_cast(bf16x8, eq[x % kWSlots]);
 #pragma unroll
             for (int i = 0; i < kWD; ++i)
@@ -543,7 +564,7 @@ __global__ void wg_finish_kernel(const float* __restrict__ c, const UnitRef* __r
         const long u = i - (long)k * units;
         const int f = (int)(u % F), s = (int)(u / ((long)F * G));
         const UnitRef ur = table[u];
-        int dyi = ur.oy + 4, dxi = ur.ox + 4;
+        int dyi = ur.oy + kWR, dxi = ur.ox + kWR;
         dyi = dyi < 0 ? 0 : (dyi > kWD - 1 ? kWD - 1 : dyi);        // (a guarded call never clamps: offsets within +-4)
         dxi = dxi < 0 ? 0 : (dxi > kWD - 1 ? kWD - 1 : dxi);
         // displacement +5 = second tap of an offset of exactly +4: its weight is 0 and C does not hold it (the load goes to the
@@ -713,4 +734,5 @@ void dense_wgrad_run(hipStream_t st, const WgradConfig& c, const float* x, const
     }
 }
 
+}  // namespace DAU_DENSE_NS
 }  // namespace dau

@@ -134,6 +134,51 @@ def test_dense_forms_under_other_prefilter_supports(shape, sigma):
         assert_parity(t.cpu().numpy(), want[key], "%s sigma %g" % (key, sigma), rel=2e-2, floor=1e-2)
 
 
+@pytest.mark.parametrize("shape", [
+    dict(N=2, S=16, F=128, G=4, H=56, W=56),
+    dict(N=3, S=20, F=40, G=3, H=30, W=45),
+    dict(N=17, S=7, F=5, G=8, H=9, W=6),
+    dict(N=2, S=33, F=130, G=6, H=28, W=28),
+    dict(N=2, S=8, F=8, G=3, H=6, W=112),
+    dict(N=18, S=9, F=33, G=3, H=19, W=72),
+])
+@pytest.mark.parametrize("unit_testing", [False, True])
+def test_dense_forms_of_radius_three(shape, unit_testing):
+    """Calls whose offsets lie within +-3 take the 7 x 7 members of the dense forms (49 taps / displacements instead of 81; the
+    device guard of the call decides between (-1, 3] and (3, 4]).  Offsets up to exactly +-3.0 -- the corners of the 7 x 7 kernel
+    and the +4 tap of weight 0 it leaves out -- against the oracle, y, dx and the dense parameter gradients; then the same plan
+    with ONE offset moved to 3.5 (the 9 x 9 members) and back."""
+    from dau_conv import _capi
+    N, S, F, G, H, W = (shape[q] for q in ("N", "S", "F", "G", "H", "W"))
+    xb, dyb, w, mu1, mu2 = _case(61, N, S, F, G, H, W, 3.0)
+    mu1.flat[0] = 3.0; mu2.flat[0] = -3.0; mu1.flat[1] = -3.0; mu2.flat[1] = 3.0
+    flags = _capi.FLAG_USE_INTERPOLATION | _capi.FLAG_IO_BF16 | _capi.FLAG_DENSE_BF16 | (_capi.FLAG_UNIT_TESTING if unit_testing else 0)
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=flags | _capi.FLAG_DENSE_WGRAD_ALWAYS)
+    assert plan.info["gather_dense_bf16"] == 2
+    dev = lambda a: torch.from_numpy(a).cuda()
+    sigma = torch.full((1, S, G, F), 0.5, device="cuda")
+    x32, dy32 = xb.float().numpy(), dyb.float().numpy()
+
+    def run_and_check(m1, m2, tag):
+        y = plan.forward(xb.cuda(), dev(w), dev(m1), dev(m2), sigma)
+        g = plan.backward(xb.cuda(), dyb.cuda(), dev(w), dev(m1), dev(m2), sigma)
+        plan.check_status()
+        assert_parity(y.float().cpu().numpy(), orc.forward(x32, w, m1, m2, 0.5), tag + "/y", rel=2e-2, floor=4e-3)
+        want = orc.backward(x32, dy32, w, m1, m2, 0.5, unit_testing=unit_testing)
+        assert_parity(g[0].float().cpu().numpy(), want["dx"], tag + "/dx", rel=2e-2, floor=4e-3)
+        for t, key in zip(g[1:], ("dw", "dmu1", "dmu2", "dsigma")):
+            assert_parity(t.cpu().numpy(), want[key], tag + "/" + key, rel=2e-2, floor=4e-3)
+        return y, g
+
+    y3, g3 = run_and_check(mu1, mu2, "r3")
+    far = mu1.copy(); far.flat[2] = 3.5
+    run_and_check(far, mu2, "r4")
+    y3b, g3b = run_and_check(mu1, mu2, "r3 again")
+    assert torch.equal(y3, y3b)
+    for a, b in zip(g3, g3b):
+        assert torch.equal(a, b)
+
+
 def test_dense_parameter_gradients_without_the_sigma_kind():
     """A call that does not want dsigma (the layer's default: dau_sigma_trainable=False; the reference's last_k_optional,
     dau_conv_backward.cpp:219) runs three of the four kinds of GEMMs: dw, dmu1, dmu2 are bit-identical to the call that wants

@@ -12,5 +12,5 @@ objs=""
 for o in dau_conv_api k_filters k_units k_direct k_gather_mfma k_gather_dot k_dense_bf16 k_dense_wgrad; do
   if [ "$o.hip" = "$src" ]; then objs="$objs ../../build/$name/variant.o"; else objs="$objs tuning_$o.o"; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/$name/libdau_conv_hip.so $objs
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../build/$name/libdau_conv_hip.so $objs tuning_r3_k_dense_bf16.o tuning_r3_k_dense_wgrad.o
 echo built build/$name
