@@ -16,8 +16,8 @@
 //
 // Layouts (HBM):
 //   XD[n][chunk][half][Hs][Ws][8]  bf16: Gaussian-blurred input, 16 input channels per chunk as two halves of 8 (one
-//       16-byte unit per position and half = the B fragment of one lane), staged position (r, c) = image (r-4, c-4),
-//       zero outside the image; Hs, Ws cover whole row / column blocks plus the 9-position tap border.
+//       16-byte unit per position and half = the B fragment of one lane), staged position (r, c) = image (r-R, c-R),
+//       zero outside the image; Hs, Ws cover whole row / column blocks plus the tap border (2 R positions).
 //   WD[chunk][tap][CoutP][16]      bf16: the dense kernel, 32 bytes per output channel (A fragments of the two lane halves).
 // Workgroup = 128 output channels x 8 rows x NSUB*8 columns, as 8 waves = 4 (32 channels each) x 2 (4 rows each), two per
 // SIMD (or 4 waves with two channel tiles each, FT = 2); a wave owns FT x NSUB accumulator tiles of 32 channels x (4 rows x

@@ -1,4 +1,5 @@
-// Densified parameter gradients on the bf16 matrix cores (DAU_FLAG_DENSE_BF16; offsets within +-4, three or more units).
+// Densified parameter gradients on the bf16 matrix cores (DAU_FLAG_DENSE_BF16; offsets within +-R, three or more units).  The file is
+// compiled for R = 4 and for R = 3 (below); the numbers in this header are those of R = 4 (R = 3: 49 displacements, 196 GEMMs).
 //
 //   r_k[s,g,f] = sum_{n,p} E'[n,f,p] * sum_{t in 2x2} b_t(s,g,f) * Xk[n,s, p + o + t]          k = w, mu1, mu2, sigma
 //             = sum_t b_t * C_k[o + t][s][f],      C_k[d][s][f] = sum_{n,p} Xk[n,s,p+d] * E'[n,f,p],   d in [-4, 4]^2 (the second tap of an offset of exactly +4 has weight 0)
@@ -15,7 +16,7 @@
 // K runs over the IMAGES innermost, so that a displacement only changes the position and every matrix fragment is one
 // aligned KiB whatever d is:
 //   XkT[k][sb][nc][H+8][WsT][2][32 s][8 n] bf16 the four derivative-filtered copies of x, staged position (r, c) = image
-//                                               (r-4, c-4), zero outside the image (wg_transpose_x + wg_filter<K> from x; prefilters
+//                                               (r-R, c-R), zero outside the image (wg_transpose_x + wg_filter<K> from x; prefilters
 //                                               wider than 9 taps: wg_stage_x from blur4_pack's fp32 copy)
 //   ET [fb][nc][H][WT'][32 f][16 n]      bf16   the error (unit_testing edge rule applied), zero for columns W..WT'-1 (WT' = whole
 //                                               row segments of an instantiated length)

@@ -110,8 +110,9 @@ enum {
                                                per-call selection from the actual offsets)             */
     DAU_FLAG_DENSE_BF16 = 1 << 6,           /* with DAU_FLAG_IO_BF16: calls whose offsets lie within +-4 run their
                                                two gather-sum passes (y, dx) as a DENSIFIED implicit GEMM on the
-                                               bf16 matrix cores (units scattered into a 10x10 kernel per channel
-                                               pair; taps and blurred activations rounded to bf16, fp32 sums),
+                                               bf16 matrix cores (units scattered into a 9x9 kernel per channel
+                                               pair -- 7x7 when the call's offsets lie within +-3, decided on the
+                                               device; taps and blurred activations rounded to bf16, fp32 sums),
                                                and -- from three units per channel on -- their parameter gradients as dense cross-correlations on the
                                                same matrix cores (filtered input and error rounded to bf16, fp32
                                                sums).  Otherwise the exact fp32 path.                        */
