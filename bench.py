@@ -330,7 +330,6 @@ def main():
             raise SystemExit("bench.py --check: the HIP path differs from the oracle: %s" % parity)
         # the oracle's OpenMP team keeps spinning on the host cores for a moment after its last parallel region; the launches of
         # a millisecond-sized step right behind it were seen to take 5x as long (C1 dense: 5.2 instead of 1.0 ms per step)
-        import time
         time.sleep(1.0)
 
     for _ in range(args.warmup):
