@@ -76,6 +76,9 @@ def parse_args():
                     help="storage type of x, y, dy, dx (BASELINE config 2 names bf16); arithmetic is fp32 either way")
     ap.add_argument("--dense", action="store_true",
                     help="with --io bf16: DAU_FLAG_DENSE_BF16 (gather-sum passes of calls with |mu| <= 4 as a densified bf16 MFMA GEMM)")
+    ap.add_argument("--split", action="store_true",
+                    help="DAU_FLAG_DENSE_SPLIT_F16: gather-sum passes of calls with |mu| <= 3 as the densified two-limb f16 MFMA GEMM "
+                         "(fp32 accuracy: the parity gate keeps the fp32 bar)")
     ap.add_argument("--no-dsigma", action="store_true",
                     help="the step does not ask for dsigma (need mask of a layer whose sigma is not trained: the reference's default, "
                          "dau_sigma_trainable=False); a side line, never the headline: BASELINE's step has all five gradients")
@@ -268,7 +271,7 @@ def main():
         x, dy = x.to(torch.bfloat16), dy.to(torch.bfloat16)
     plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, number_units_ignore=ignore, algo=args.algo,
                       flags=_capi.FLAG_USE_INTERPOLATION | (_capi.FLAG_IO_BF16 if args.io == "bf16" else 0) |
-                            (_capi.FLAG_DENSE_BF16 if args.dense else 0),
+                            (_capi.FLAG_DENSE_BF16 if args.dense else 0) | (_capi.FLAG_DENSE_SPLIT_F16 if args.split else 0),
                       sigma_hint=0.5, mu_learning_rate_factor=1.0)
     from dau_conv.distributed import OverlappedBackward
     exchange = OverlappedBackward((1, S, G, F), dev) if use_dist else None

@@ -95,6 +95,10 @@ struct BucketSet {
     bool dense3_ok = false, wgrad3_ok = false;
     DenseConfig dense3_fwd, dense3_dx;
     WgradConfig wgrad3;
+    // DAU_FLAG_DENSE_SPLIT_F16, bucket 4 only: calls whose offsets lie within +-3 run the gather-sum passes as the two-limb f16
+    // GEMM (k_dense_split.hip: fp32 accuracy); the device guard (-1, 3] decides, everything else takes the exact kernels
+    bool split3_ok = false;
+    DenseConfig split3_fwd, split3_dx;
     // Batch slabs.  Every pass stages its whole input before it gathers; where that staged copy would exceed the workspace
     // budget (DAU_WORKSPACE_BUDGET_GB at plan creation, default 12: only the 512 x 512 configurations get there) the pass
     // runs slab by slab over the batch -- the configs above are made for `slab_*` images, the passes loop -- so that the
@@ -185,7 +189,7 @@ int pick_candidates(const dau_conv_plan* p, const Status* dev_status, int pass_k
     out[0] = Candidate{top, Guard{nullptr, 0.0f, 0.0f}};
     if (!p->dynamic) return 1;
     const BucketSet& s0 = p->sets[0];
-    const bool d3 = pass_kind == 0 ? s0.dense3_ok : s0.wgrad3_ok;
+    const bool d3 = pass_kind == 0 ? (s0.dense3_ok || s0.split3_ok) : s0.wgrad3_ok;
     if (p->nsets < 2 && !d3) return 1;
     const BucketSet* dense = (pass_kind == 0 ? s0.dense_ok : s0.wgrad_ok) ? &s0 : nullptr;
     const BucketSet* hinted = nullptr;
@@ -230,6 +234,7 @@ int ensure_attrs(const dau_conv_plan* p) {
         if (p->sets[i].wgrad_ok) r4::dense_wgrad_init(p->sets[i].wgrad);
         if (p->sets[i].dense3_ok) { r3::dense_gather_init(p->sets[i].dense3_fwd); r3::dense_gather_init(p->sets[i].dense3_dx); }
         if (p->sets[i].wgrad3_ok) r3::dense_wgrad_init(p->sets[i].wgrad3);
+        if (p->sets[i].split3_ok) { s3::split_gather_init(p->sets[i].split3_fwd); s3::split_gather_init(p->sets[i].split3_dx); }
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return fail(DAU_INTERNAL, "raising the dynamic-LDS limit of the bucket-%d kernels failed: %s", p->sets[i].bucket,
@@ -260,6 +265,7 @@ FwdWs carve_forward(const dau_conv_plan* p, void* ws) {
             if (p->sets[i].fwd_ok) need = std::max(need, tiled_gather_workspace_bytes(p->sets[i].tiled_fwd));
             if (p->sets[i].dense_ok) need = std::max(need, r4::dense_gather_workspace_bytes(p->sets[i].dense_fwd));
             if (p->sets[i].dense3_ok) need = std::max(need, r3::dense_gather_workspace_bytes(p->sets[i].dense3_fwd));
+            if (p->sets[i].split3_ok) need = std::max(need, s3::split_gather_workspace_bytes(p->sets[i].split3_fwd));
         }
         w.tiled = c.take<char>(need);
     } else {
@@ -309,6 +315,7 @@ BwdWs carve_backward(const dau_conv_plan* p, void* ws) {
             if (p->sets[i].fwd_ok) need = std::max(need, tiled_gather_workspace_bytes(p->sets[i].tiled_dx));
             if (p->sets[i].dense_ok) need = std::max(need, r4::dense_gather_workspace_bytes(p->sets[i].dense_dx));
             if (p->sets[i].dense3_ok) need = std::max(need, r3::dense_gather_workspace_bytes(p->sets[i].dense3_dx));
+            if (p->sets[i].split3_ok) need = std::max(need, s3::split_gather_workspace_bytes(p->sets[i].split3_dx));
         }
         w.tiled_dx = c.take<char>(need);
     } else {
@@ -385,6 +392,7 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
         bs.bucket = b;
         // slab candidates: the whole batch, then its even divisors (image pairs stay together), largest first
         const bool want_dense = (desc->flags & DAU_FLAG_DENSE_BF16) && desc->algo != DAU_ALGO_DIRECT;
+        const bool want_split = (desc->flags & DAU_FLAG_DENSE_SPLIT_F16) && desc->algo != DAU_ALGO_DIRECT;
         auto configure_gather = [&](int n) {
             bs.fwd_ok = tiled_gather_configure(n, s.S, s.F, s.G, s.H, s.W, b, blur_k, bf16, &bs.tiled_fwd) &&
                         tiled_gather_configure(n, s.F, s.S, s.G, s.H, s.W, b, blur_k, bf16, &bs.tiled_dx);
@@ -394,8 +402,12 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
             bs.dense3_ok = bs.dense_ok && b == 4 && DAU_TUNE_INT("DAU_DENSE_R3", 1) != 0 &&
                            r3::dense_gather_configure(n, s.S, s.F, s.G, s.H, s.W, 3, blur_k, bf16, &bs.dense3_fwd) &&
                            r3::dense_gather_configure(n, s.F, s.S, s.G, s.H, s.W, 3, blur_k, bf16, &bs.dense3_dx);
+            bs.split3_ok = want_split && bs.fwd_ok && b == 4 &&
+                           s3::split_gather_configure(n, s.S, s.F, s.G, s.H, s.W, 3, blur_k, bf16, &bs.split3_fwd) &&
+                           s3::split_gather_configure(n, s.F, s.S, s.G, s.H, s.W, 3, blur_k, bf16, &bs.split3_dx);
             size_t need = 0;
             if (bs.fwd_ok) need = std::max(tiled_gather_workspace_bytes(bs.tiled_fwd), tiled_gather_workspace_bytes(bs.tiled_dx));
+            if (bs.split3_ok) need = std::max(need, std::max(s3::split_gather_workspace_bytes(bs.split3_fwd), s3::split_gather_workspace_bytes(bs.split3_dx)));
             if (bs.dense_ok) need = std::max(need, std::max(r4::dense_gather_workspace_bytes(bs.dense_fwd), r4::dense_gather_workspace_bytes(bs.dense_dx)));
             if (bs.dense3_ok) need = std::max(need, std::max(r3::dense_gather_workspace_bytes(bs.dense3_fwd), r3::dense_gather_workspace_bytes(bs.dense3_dx)));
             return need;
@@ -433,6 +445,10 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
         delete p;
         return fail(DAU_INVALID_ARGUMENT, "DAU_FLAG_DENSE_BF16 needs DAU_FLAG_IO_BF16 (it is the bf16 layer's gather-sum)");
     }
+    if ((desc->flags & DAU_FLAG_DENSE_SPLIT_F16) && (desc->flags & DAU_FLAG_DENSE_BF16)) {
+        delete p;
+        return fail(DAU_INVALID_ARGUMENT, "DAU_FLAG_DENSE_SPLIT_F16 and DAU_FLAG_DENSE_BF16 exclude each other");
+    }
     if ((desc->flags & (DAU_FLAG_DENSE_WGRAD_NEVER | DAU_FLAG_DENSE_WGRAD_ALWAYS)) &&
         (!(desc->flags & DAU_FLAG_DENSE_BF16) || (desc->flags & DAU_FLAG_DENSE_WGRAD_NEVER && desc->flags & DAU_FLAG_DENSE_WGRAD_ALWAYS))) {
         delete p;
@@ -452,7 +468,7 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
     // dynamic bucket selection: tiled kernels, more than one bucket (or the two radii of the dense forms), not switched off (DAU_FLAG_STATIC_BUCKET; tuning build:
     // DAU_DYNAMIC_BUCKET=0 in the environment at plan creation).  The pinned status mirror needs a device; without one
     // (header-only checks on a CPU box) the plan simply has no hint.
-    p->dynamic = (p->nsets > 1 || p->sets[0].dense3_ok) && !(desc->flags & DAU_FLAG_STATIC_BUCKET) && DAU_TUNE_INT("DAU_DYNAMIC_BUCKET", 1) != 0 &&
+    p->dynamic = (p->nsets > 1 || p->sets[0].dense3_ok || p->sets[0].split3_ok) && !(desc->flags & DAU_FLAG_STATIC_BUCKET) && DAU_TUNE_INT("DAU_DYNAMIC_BUCKET", 1) != 0 &&
                  (p->algo_fwd == DAU_ALGO_TILED || p->algo_bwd == DAU_ALGO_TILED);
     void* hs = nullptr;
     if (hipHostMalloc(&hs, sizeof(HostStatus), hipHostMallocDefault) == hipSuccess && hs) {
@@ -524,6 +540,7 @@ int dau_conv_plan_get_info(const dau_conv_plan* plan, dau_conv_plan_info* info) 
     info->dot_region = plan->top().dot_ok ? plan->top().tiled_dot.region_cols * 100 + plan->top().tiled_dot.region_rows : 0;
     info->gather_fblock = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.fblock : 0;
     info->gather_variant = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.variant : -1;
+    info->gather_dense_split = (plan->sets[0].split3_ok && plan->dynamic && plan->algo_fwd == DAU_ALGO_TILED) ? 1 : 0;
     return DAU_OK;
 }
 
@@ -558,6 +575,12 @@ int dau_conv_forward(const dau_conv_plan* p, void* stream, const float* x, const
             for (int n0 = 0; n0 < s.N; n0 += bs.slab_gather) {             // one slab unless the staged copy exceeds the budget
                 const float* xs = slab_ptr(x, (size_t)n0 * s.S * s.H * s.W, esize);
                 float* ys = slab_ptr(y, (size_t)n0 * s.F * s.H * s.W, esize);
+                if (cand[ci].r3 && bs.split3_ok) {                         // offsets within +-3: two-limb f16 GEMM, fp32 accuracy
+                    s3::split_gather_prepare(st, bs.split3_fwd, xs, ws.filters, false, ws.table, ws.tiled, cand[ci].guard);
+                    ProfScope prof(p, 0, st);
+                    s3::split_gather_run(st, bs.split3_fwd, ys, ws.tiled, cand[ci].guard);
+                    continue;
+                }
                 if (cand[ci].r3) {                                         // bf16 layer, offsets within +-3: 7 x 7 dense kernel
                     r3::dense_gather_prepare(st, bs.dense3_fwd, xs, ws.filters, false, ws.table, ws.tiled, cand[ci].guard);
                     ProfScope prof(p, 0, st);
@@ -680,6 +703,12 @@ int dau_conv_backward(const dau_conv_plan* p, void* stream, const float* x, cons
                 for (int n0 = 0; n0 < s.N; n0 += bs.slab_gather) {
                     const float* dys = slab_ptr(dy, (size_t)n0 * s.F * s.H * s.W, esize);
                     float* dxs = slab_ptr(dx, (size_t)n0 * s.S * s.H * s.W, esize);
+                    if (cand[ci].r3 && bs.split3_ok) {
+                        s3::split_gather_prepare(st, bs.split3_dx, dys, ws.filters, true, ws.table_t, ws.tiled_dx, cand[ci].guard);
+                        ProfScope prof(p, 1, st);
+                        s3::split_gather_run(st, bs.split3_dx, dxs, ws.tiled_dx, cand[ci].guard);
+                        continue;
+                    }
                     if (cand[ci].r3) {
                         r3::dense_gather_prepare(st, bs.dense3_dx, dys, ws.filters, true, ws.table_t, ws.tiled_dx, cand[ci].guard);
                         ProfScope prof(p, 1, st);

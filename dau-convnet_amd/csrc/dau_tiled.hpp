@@ -64,6 +64,19 @@ struct DenseConfig {
 DAU_DECLARE_DENSE_GATHER(r4)
 DAU_DECLARE_DENSE_GATHER(r3)
 
+// Densified gather-sum at fp32 accuracy (k_dense_split.hip): the same dense form with both operands split into two binary16
+// limbs, three f16 MFMAs per tap -- fp32 or bf16 activations, inside the fp32 parity bar; namespace s3 = offsets within +-3.
+#define DAU_DECLARE_SPLIT_GATHER(NS)                                                                                           \
+    namespace NS {                                                                                                            \
+    bool split_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, bool bf16, DenseConfig* cfg); \
+    size_t split_gather_workspace_bytes(const DenseConfig& cfg);                                                              \
+    void split_gather_init(const DenseConfig& cfg);                                                                           \
+    void split_gather_prepare(hipStream_t st, const DenseConfig& cfg, const float* in, const float* filters, bool mirrored,   \
+                              const UnitRef* table, void* workspace, const Guard& guard);                                     \
+    void split_gather_run(hipStream_t st, const DenseConfig& cfg, float* out, void* workspace, const Guard& guard);           \
+    }
+DAU_DECLARE_SPLIT_GATHER(s3)
+
 struct TiledDotConfig {
     Shape sh;
     int R, blur_k;

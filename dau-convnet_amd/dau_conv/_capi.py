@@ -24,6 +24,7 @@ FLAG_STATIC_BUCKET = 1 << 5   # always the kernels of the bucket max_kernel_size
 FLAG_DENSE_BF16 = 1 << 6      # with FLAG_IO_BF16: gather-sum passes of calls with |mu| <= 4 as a densified bf16 MFMA GEMM
 FLAG_DENSE_WGRAD_NEVER = 1 << 7    # with FLAG_DENSE_BF16: parameter gradients always through the exact fp32 gather-dot
 FLAG_DENSE_WGRAD_ALWAYS = 1 << 8   # with FLAG_DENSE_BF16: dense parameter gradients from one unit per channel on (default: three)
+FLAG_DENSE_SPLIT_F16 = 1 << 9      # gather-sum passes of calls with |mu| <= 3 as a densified two-limb f16 MFMA GEMM at fp32 accuracy
 
 ALGO_AUTO, ALGO_DIRECT, ALGO_TILED = 0, 1, 2
 PASS_FORWARD, PASS_BACKWARD = 1, 2
@@ -60,7 +61,7 @@ class _Desc(ctypes.Structure):
 class _Info(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ("offset_bucket", "blur_support", "algo_forward", "algo_backward", "drop_last_col", "drop_last_row",
-                 "gather_patch", "gather_stack", "dot_windows", "gather_windows", "bucket_sets", "gather_dense_bf16", "batch_slab_gather", "batch_slab_dot", "dot_region", "gather_fblock", "gather_variant")]
+                 "gather_patch", "gather_stack", "dot_windows", "gather_windows", "bucket_sets", "gather_dense_bf16", "batch_slab_gather", "batch_slab_dot", "dot_region", "gather_fblock", "gather_variant", "gather_dense_split")]
 
 
 def _load():
@@ -89,7 +90,7 @@ def _load():
     lib.dau_conv_filter_support.restype = ctypes.c_int
     lib.dau_conv_profile_begin.argtypes = [vp]
     lib.dau_conv_profile_end.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]
-    if lib.dau_conv_abi_version() != 3:
+    if lib.dau_conv_abi_version() != 4:
         raise ImportError("dau_conv: ABI version mismatch in %s" % _LIB_PATH)
     return lib
 

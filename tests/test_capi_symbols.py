@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(LIB)
     for name in declared_symbols():
         assert hasattr(lib, name), "missing export %s" % name
-    assert lib.dau_conv_abi_version() == 3
+    assert lib.dau_conv_abi_version() == 4
 
 
 def test_release_library_reads_no_tuning_knobs():
