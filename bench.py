@@ -77,8 +77,13 @@ def parse_args():
     ap.add_argument("--dense", action="store_true",
                     help="with --io bf16: DAU_FLAG_DENSE_BF16 (gather-sum passes of calls with |mu| <= 4 as a densified bf16 MFMA GEMM)")
     ap.add_argument("--split", action="store_true",
-                    help="DAU_FLAG_DENSE_SPLIT_F16: gather-sum passes of calls with |mu| <= 3 as the densified two-limb f16 MFMA GEMM "
-                         "(fp32 accuracy: the parity gate keeps the fp32 bar)")
+                    help="DAU_FLAG_DENSE_SPLIT_F16: the two-limb f16 dense gather-sum members of all three radii whatever the unit "
+                         "count (default: the library's choice -- the radii that pay; fp32 accuracy, the parity gate keeps the fp32 bar)")
+    ap.add_argument("--no-split", action="store_true",
+                    help="DAU_FLAG_NO_DENSE_SPLIT: the exact fp32 gather (v_mfma_f32_4x4x1) for every call")
+    ap.add_argument("--mu-range", type=float, default=None, metavar="M",
+                    help="draw the offsets from U(-M, M) instead of the workload's own range (BASELINE: 3): which gather-sum member a "
+                         "call takes depends on its largest offset (dense radius 2 / 3 / 4, else the exact gather)")
     ap.add_argument("--no-dsigma", action="store_true",
                     help="the step does not ask for dsigma (need mask of a layer whose sigma is not trained: the reference's default, "
                          "dau_sigma_trainable=False); a side line, never the headline: BASELINE's step has all five gradients")
@@ -92,16 +97,26 @@ def parse_args():
                     help="offset distribution: uniform = mu ~ U(-m, m) per unit (the reference tests' and BASELINE's synthetic "
                          "data; the worst case for the binned large-offset kernels), grid = the units of every channel pair on "
                          "the regular grid the reference layer initialises them on (DAUGridMean) + U(-JITTER, JITTER), default 1")
-    ap.add_argument("--check", type=int, default=0, metavar="IMAGES",
-                    help="parity gate before timing: y and dx of the first IMAGES images against the CPU oracle")
-    ap.add_argument("--check-params", type=int, default=0, metavar="CHANNELS",
+    ap.add_argument("--check", type=int, default=None, metavar="IMAGES",
+                    help="parity gate before timing: y and dx of the first IMAGES images against the CPU oracle (default 1; "
+                         "--no-check: none)")
+    ap.add_argument("--check-params", type=int, default=None, metavar="CHANNELS",
                     help="with --check: also dw, dmu1, dmu2, dsigma of the first CHANNELS output channels (sums over the WHOLE "
-                         "batch: the oracle runs all N images on that slice of the output channels)")
+                         "batch: the oracle runs all N images on that slice of the output channels; default 4)")
+    ap.add_argument("--no-check", action="store_true", help="no parity gate in front of the timing (the line then says parity_gate: null)")
     ap.add_argument("--steady-seconds", type=float, default=8.0,
                     help="after the timed steps, keep stepping for about this long (at most 200 steps) and report the mean step "
                          "time of that run as roofline.steady_state_ms: the kernels are power limited and the headline's few "
                          "steps are over before the chip has warmed up (0: skip)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    # the gate is ON by default (about 1.5 s of oracle time at the north-star size, before the warm-up): the driver's fixed
+    # command line must carry a parity verdict too
+    if args.no_check:
+        args.check, args.check_params = 0, 0
+    else:
+        args.check = 1 if args.check is None else args.check
+        args.check_params = (4 if args.check > 0 else 0) if args.check_params is None else args.check_params
+    return args
 
 
 def launch_ranks(args):
@@ -235,6 +250,10 @@ def main():
         wl = dict(N=int(v[0]), S=int(v[1]), F=int(v[2]), H=int(v[3]), W=int(v[4]), G=int(v[5]), k=int(v[6]),
                   m=float(v[7]) if len(v) > 7 else 3.0, label="ad-hoc " + args.shape)
         wl_key = "adhoc:" + args.shape
+    if args.mu_range is not None:
+        wl["m"] = float(args.mu_range)
+        wl["label"] += " [offsets ~ U(-%g, %g)]" % (wl["m"], wl["m"])
+        wl_key += ":m%g" % wl["m"]
     N, S, F, H, W, G, k, m = (wl[q] for q in ("N", "S", "F", "H", "W", "G", "k", "m"))
     ignore = int(wl.get("ignore", 0))
     G_live = G - ignore
@@ -271,7 +290,8 @@ def main():
         x, dy = x.to(torch.bfloat16), dy.to(torch.bfloat16)
     plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, number_units_ignore=ignore, algo=args.algo,
                       flags=_capi.FLAG_USE_INTERPOLATION | (_capi.FLAG_IO_BF16 if args.io == "bf16" else 0) |
-                            (_capi.FLAG_DENSE_BF16 if args.dense else 0) | (_capi.FLAG_DENSE_SPLIT_F16 if args.split else 0),
+                            (_capi.FLAG_DENSE_BF16 if args.dense else 0) | (_capi.FLAG_DENSE_SPLIT_F16 if args.split else 0) |
+                            (_capi.FLAG_NO_DENSE_SPLIT if args.no_split else 0),
                       sigma_hint=0.5, mu_learning_rate_factor=1.0)
     from dau_conv.distributed import OverlappedBackward
     exchange = OverlappedBackward((1, S, G, F), dev) if use_dist else None
@@ -358,16 +378,23 @@ def main():
         prof = {}
     else:
         plan.profile_begin()
+        if exchange is not None:
+            exchange.measure_exposed(True)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         fence()
         elapsed = time.perf_counter() - t0
         prof = plan.profile_end()
+        if exchange is not None:
+            exposed_total, exposed_joins = exchange.exposed_ms()
+            exchange.measure_exposed(False)
+    exposed_ms = None
     if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, (exposed_total / max(exposed_joins, 1)) if not args.graph else 0.0], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        exposed_ms = float(t[1].item())
     # thermal steady state: NOT part of the headline (value / ms_per_step come from exactly --steps steps above); the same
     # step repeated for several seconds, timed as a whole
     steady = None
@@ -393,11 +420,21 @@ def main():
     unit_px = float(G_live) * N * H * W * S * F
     flops = {"gather_sum_fwd": 8.0 * unit_px, "gather_sum_dx": 8.0 * unit_px, "gather_dot": 16.0 * unit_px}
     dense = bool(args.dense and plan.info.get("gather_dense_bf16"))
+    # the two-limb f16 dense member a call with these offsets takes for its gather-sum passes (0: the exact gather)
+    split_bits = int(plan.info.get("gather_dense_split", 0))
+    mu_max = float(max(mu1.abs().max().item(), mu2.abs().max().item()))
+    split_r = next((r for r in (2, 3, 4) if (split_bits >> r) & 1 and mu_max <= r), 0)
     kern = {}
     for name, (ms, passes) in prof.items():
         if passes:
             avg = ms / passes
             kern[name] = dict(avg_ms=round(avg, 4), passes=passes, tflops=round(flops[name] / (avg * 1e-3) / 1e12, 2))
+            if split_r and name != "gather_dot":
+                taps = (2 * split_r + 1) ** 2
+                ex = 2.0 * taps * 3 * N * H * W * S * F / (avg * 1e-3) / 1e12
+                kern[name].update(form="two-limb f16 dense GEMM, radius %d (%d taps x 3 limb products)" % (split_r, taps),
+                                  executed_tflops=round(ex, 1), executed_frac_of_f16_peak=round(ex / BF16_PEAK_TFLOPS, 4),
+                                  note="tflops = ALGORITHMIC gather FLOPs / time (may exceed the fp32 roof: the pass runs on the f16 matrix cores)")
     dominant = max(kern, key=lambda n: kern[n]["avg_ms"]) if kern else None
     roofline = None
     if dominant:
@@ -415,6 +452,11 @@ def main():
             peak = BF16_PEAK_TFLOPS
             roof_note = ("densified bf16 form: achieved = executed dense FLOPs (2*%d*N*H*W*S*F) / time against the dense bf16 "
                          "MFMA peak; kernels[*].tflops stay algorithmic (gather form)" % int(taps))
+        if split_r and dominant != "gather_dot":
+            ach = kern[dominant]["executed_tflops"]
+            peak = BF16_PEAK_TFLOPS
+            roof_note = ("two-limb f16 dense form: achieved = executed dense FLOPs / time against the dense f16 MFMA peak; "
+                         "kernels[*].tflops stay algorithmic (gather form)")
         roofline = dict(bound="mfma", kernel=dominant, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
                         frac=round(ach / peak, 4), traffic=traffic, traffic_unit="GB per pass",
                         traffic_note=traffic_note, kernels=kern,
@@ -496,16 +538,22 @@ def main():
                    ranks_seen=(dist.get_world_size() if use_dist else 1),
                    comm=(dict(backend=("rccl" if backend == "nccl" else backend), communicator_size=dist.get_world_size(),
                               exchange="all_reduce(sum) of raw param-grad sums [4,S,G,F] = %d floats per step, async under the dx pass; finalize after"
-                              % (4 * S * G * F)) if use_dist else None),
+                              % (4 * S * G * F), bytes_per_step=16 * S * G * F,
+                              exposed_ms=(None if exposed_ms is None else round(exposed_ms, 4)),
+                              exposed_note="mean time per step the compute stream stands still at the join with the all-reduce (HIP events "
+                                           "around the wait, after the dx pass was enqueued; max over ranks): what of the exchange the dx pass does not hide") if use_dist else None),
                    config=dict(workload=wl["label"] + (" [bf16 activations in HBM]" if args.io == "bf16" else "") +
                                (" [offsets: %s instead of U(-m,m)]" % args.offsets if args.offsets != "uniform" else "") +
                                (" [gather-sum passes%s as densified bf16 MFMA GEMM]" % (" and parameter gradients" if dense and int(plan.info.get("gather_dense_bf16", 0)) == 2 else "") if dense else "") +
+                               (" [gather-sum passes: two-limb f16 dense GEMM of radius %d, fp32 accuracy; max|mu| = %.2f]" % (split_r, mu_max) if split_r else
+                                (" [gather-sum passes: exact fp32 gather; max|mu| = %.2f]" % mu_max)) +
                                (" [SIDE LINE: the step does not ask for dsigma (dx, dw, dmu1, dmu2 only)]" if args.no_dsigma else "") +
                                (" [one step captured into a HIP graph, replays timed]" if args.graph and not use_dist else "") +
                                ("" if backend == "nccl" else " [REHEARSAL: %s backend, ranks share GPUs]" % backend),
                                global_batch=N * world, parallelism="dp%d" % world,
                                algo_forward=plan.info["algo_forward"], algo_backward=plan.info["algo_backward"],
-                               static_offset_bucket=plan.info["offset_bucket"], bucket_sets=plan.info["bucket_sets"]),
+                               static_offset_bucket=plan.info["offset_bucket"], bucket_sets=plan.info["bucket_sets"],
+                               gather_dense_split_radii=[r for r in (2, 3, 4) if (split_bits >> r) & 1]),
                    roofline=roofline, cpu_baseline=cpu, layer=layer, parity_gate=parity, lib=lib_fingerprint())
         print(json.dumps(out))
     if use_dist:

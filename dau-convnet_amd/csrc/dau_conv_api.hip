@@ -95,10 +95,12 @@ struct BucketSet {
     bool dense3_ok = false, wgrad3_ok = false;
     DenseConfig dense3_fwd, dense3_dx;
     WgradConfig wgrad3;
-    // DAU_FLAG_DENSE_SPLIT_F16, bucket 4 only: calls whose offsets lie within +-3 run the gather-sum passes as the two-limb f16
-    // GEMM (k_dense_split.hip: fp32 accuracy); the device guard (-1, 3] decides, everything else takes the exact kernels
-    bool split3_ok = false;
-    DenseConfig split3_fwd, split3_dx;
+    // bucket 4 only: calls whose offsets lie within +-2 / +-3 / +-4 run the gather-sum passes as the two-limb f16 GEMM of that
+    // radius (k_dense_split.hip: fp32 accuracy; index r - 2); the call's device guard decides, everything else takes the exact
+    // kernels.  Which radii a plan holds: those that pay for its unit count (split_pays below), all / none by flag.
+    bool split_ok[3] = {false, false, false};
+    DenseConfig split_fwd[3], split_dx[3];
+    bool any_split() const { return split_ok[0] || split_ok[1] || split_ok[2]; }
     // Batch slabs.  Every pass stages its whole input before it gathers; where that staged copy would exceed the workspace
     // budget (DAU_WORKSPACE_BUDGET_GB at plan creation, default 12: only the 512 x 512 configurations get there) the pass
     // runs slab by slab over the batch -- the configs above are made for `slab_*` images, the passes loop -- so that the
@@ -107,6 +109,32 @@ struct BucketSet {
 };
 constexpr int kBuckets[] = {4, 8, 16, 18, 20, 24, 32};
 constexpr int kNumBuckets = 7;
+
+// the two-limb f16 dense gather-sum, one set of entry points per offset radius (index r - 2)
+struct SplitFns {
+    bool (*configure)(int, int, int, int, int, int, int, int, bool, DenseConfig*);
+    size_t (*workspace_bytes)(const DenseConfig&);
+    void (*init)(const DenseConfig&);
+    void (*prepare)(hipStream_t, const DenseConfig&, const float*, const float*, bool, const UnitRef*, void*, const Guard&);
+    void (*run)(hipStream_t, const DenseConfig&, float*, void*, const Guard&);
+};
+const SplitFns kSplit[3] = {
+    {s2::split_gather_configure, s2::split_gather_workspace_bytes, s2::split_gather_init, s2::split_gather_prepare, s2::split_gather_run},
+    {s3::split_gather_configure, s3::split_gather_workspace_bytes, s3::split_gather_init, s3::split_gather_prepare, s3::split_gather_run},
+    {s4::split_gather_configure, s4::split_gather_workspace_bytes, s4::split_gather_init, s4::split_gather_prepare, s4::split_gather_run},
+};
+// Does the dense form of radius r pay against the exact gather?  MFMA work per pass in fp32-rate MAC units: the dense GEMM runs
+// (2r+1)^2 taps x 3 limb products at 16x the fp32 rate over the PADDED tile (8-row / 8-column blocks, 128 output channels, 16 input
+// channels) plus its staging, at ~55 % of the f16 roof; the exact gather 4 MACs per live unit at ~60 % of the fp32 roof (measured
+// at the north-star shape: 5.2 + 0.5 ms against 8.9 ms at radius 3, four units).  Radius 2 pays from two units per channel pair on
+// whole tiles, radius 3 from three, radius 4 from five.
+bool split_pays(int r, int Cin, int Cout, int G_live, int H, int W) {
+    const double taps = (2.0 * r + 1) * (2.0 * r + 1);
+    const double hp = (H + 7) / 8 * 8, wp = (W + 7) / 8 * 8, fp = (Cout + 127) / 128 * 128, sp = (Cin + 15) / 16 * 16;
+    const double dense = hp * wp * (fp * sp * taps * 3.0 / 16.0 / 0.55 + sp * 430.0);
+    const double exact = (double)H * W * Cout * Cin * G_live * 4.0 / 0.60;
+    return dense < 0.9 * exact;
+}
 
 struct dau_conv_plan {
     dau_conv_desc d;
@@ -170,7 +198,8 @@ struct ProfScope {
 struct Candidate {
     const BucketSet* set;
     Guard guard;
-    bool r3 = false;          // the set's radius-3 dense member (sets[0] only)
+    bool r3 = false;          // the set's radius-3 dense bf16 member (sets[0] only)
+    int split_r = 0;          // 2, 3, 4: the set's two-limb f16 dense member of that radius (sets[0], gather-sum passes only)
 };
 
 void clear_host_status(const dau_conv_plan* p) {
@@ -183,14 +212,15 @@ void clear_host_status(const dau_conv_plan* p) {
 // A plan with DAU_FLAG_DENSE_BF16 has one member whose ARITHMETIC differs (bucket 4: bf16 products): that member is enqueued,
 // guarded by (-1, 4], on every call, hint or no hint, so that which arithmetic a call gets depends on its own offsets only.
 // The dense forms exist for |mu| <= 3 as well (49 taps instead of 81): that member goes first, guarded by (-1, 3].
-constexpr int kMaxCandidates = 4;
+constexpr int kMaxCandidates = 6;
 int pick_candidates(const dau_conv_plan* p, const Status* dev_status, int pass_kind, Candidate out[kMaxCandidates]) {
     const BucketSet* top = &p->top();
     out[0] = Candidate{top, Guard{nullptr, 0.0f, 0.0f}};
     if (!p->dynamic) return 1;
     const BucketSet& s0 = p->sets[0];
-    const bool d3 = pass_kind == 0 ? (s0.dense3_ok || s0.split3_ok) : s0.wgrad3_ok;
-    if (p->nsets < 2 && !d3) return 1;
+    const bool d3 = pass_kind == 0 ? s0.dense3_ok : s0.wgrad3_ok;
+    const bool split = pass_kind == 0 && s0.any_split();
+    if (p->nsets < 2 && !d3 && !split) return 1;
     const BucketSet* dense = (pass_kind == 0 ? s0.dense_ok : s0.wgrad_ok) ? &s0 : nullptr;
     const BucketSet* hinted = nullptr;
     if (p->host_status && p->nsets >= 2) {
@@ -208,9 +238,14 @@ int pick_candidates(const dau_conv_plan* p, const Status* dev_status, int pass_k
     }
     int n = 0;
     float lo = -1.0f;
+    // the members with an arithmetic of their own are candidates of EVERY call (hint or no hint), smallest radius first: which
+    // arithmetic a call gets depends on its own offsets only
+    if (split)
+        for (int r = 2; r <= 4; ++r)
+            if (s0.split_ok[r - 2]) { out[n] = Candidate{&s0, Guard{dev_status, lo, (float)r}}; out[n++].split_r = r; lo = (float)r; }
     if (d3) { out[n] = Candidate{&s0, Guard{dev_status, lo, 3.0f}}; out[n++].r3 = true; lo = 3.0f; }
     if (dense && hinted != dense && dense != top) { out[n++] = Candidate{dense, Guard{dev_status, lo, (float)dense->bucket}}; lo = (float)dense->bucket; }
-    if (hinted) { out[n++] = Candidate{hinted, Guard{dev_status, lo, (float)hinted->bucket}}; lo = (float)hinted->bucket; }
+    if (hinted && lo < (float)hinted->bucket) { out[n++] = Candidate{hinted, Guard{dev_status, lo, (float)hinted->bucket}}; lo = (float)hinted->bucket; }
     if (n == 0) return 1;                                    // no hint, nothing dense: the static set, unguarded
     out[n++] = Candidate{top, Guard{dev_status, lo, INFINITY}};
     return n;
@@ -234,7 +269,8 @@ int ensure_attrs(const dau_conv_plan* p) {
         if (p->sets[i].wgrad_ok) r4::dense_wgrad_init(p->sets[i].wgrad);
         if (p->sets[i].dense3_ok) { r3::dense_gather_init(p->sets[i].dense3_fwd); r3::dense_gather_init(p->sets[i].dense3_dx); }
         if (p->sets[i].wgrad3_ok) r3::dense_wgrad_init(p->sets[i].wgrad3);
-        if (p->sets[i].split3_ok) { s3::split_gather_init(p->sets[i].split3_fwd); s3::split_gather_init(p->sets[i].split3_dx); }
+        for (int r = 0; r < 3; ++r)
+            if (p->sets[i].split_ok[r]) { kSplit[r].init(p->sets[i].split_fwd[r]); kSplit[r].init(p->sets[i].split_dx[r]); }
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess)
             return fail(DAU_INTERNAL, "raising the dynamic-LDS limit of the bucket-%d kernels failed: %s", p->sets[i].bucket,
@@ -265,7 +301,8 @@ FwdWs carve_forward(const dau_conv_plan* p, void* ws) {
             if (p->sets[i].fwd_ok) need = std::max(need, tiled_gather_workspace_bytes(p->sets[i].tiled_fwd));
             if (p->sets[i].dense_ok) need = std::max(need, r4::dense_gather_workspace_bytes(p->sets[i].dense_fwd));
             if (p->sets[i].dense3_ok) need = std::max(need, r3::dense_gather_workspace_bytes(p->sets[i].dense3_fwd));
-            if (p->sets[i].split3_ok) need = std::max(need, s3::split_gather_workspace_bytes(p->sets[i].split3_fwd));
+            for (int r = 0; r < 3; ++r)
+                if (p->sets[i].split_ok[r]) need = std::max(need, kSplit[r].workspace_bytes(p->sets[i].split_fwd[r]));
         }
         w.tiled = c.take<char>(need);
     } else {
@@ -315,7 +352,8 @@ BwdWs carve_backward(const dau_conv_plan* p, void* ws) {
             if (p->sets[i].fwd_ok) need = std::max(need, tiled_gather_workspace_bytes(p->sets[i].tiled_dx));
             if (p->sets[i].dense_ok) need = std::max(need, r4::dense_gather_workspace_bytes(p->sets[i].dense_dx));
             if (p->sets[i].dense3_ok) need = std::max(need, r3::dense_gather_workspace_bytes(p->sets[i].dense3_dx));
-            if (p->sets[i].split3_ok) need = std::max(need, s3::split_gather_workspace_bytes(p->sets[i].split3_dx));
+            for (int r = 0; r < 3; ++r)
+                if (p->sets[i].split_ok[r]) need = std::max(need, kSplit[r].workspace_bytes(p->sets[i].split_dx[r]));
         }
         w.tiled_dx = c.take<char>(need);
     } else {
@@ -392,7 +430,9 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
         bs.bucket = b;
         // slab candidates: the whole batch, then its even divisors (image pairs stay together), largest first
         const bool want_dense = (desc->flags & DAU_FLAG_DENSE_BF16) && desc->algo != DAU_ALGO_DIRECT;
-        const bool want_split = (desc->flags & DAU_FLAG_DENSE_SPLIT_F16) && desc->algo != DAU_ALGO_DIRECT;
+        const bool split_forced = (desc->flags & DAU_FLAG_DENSE_SPLIT_F16) != 0;
+        const bool split_allowed = !(desc->flags & (DAU_FLAG_NO_DENSE_SPLIT | DAU_FLAG_DENSE_BF16)) && desc->algo != DAU_ALGO_DIRECT &&
+                                   DAU_TUNE_INT("DAU_DENSE_SPLIT", 1) != 0;
         auto configure_gather = [&](int n) {
             bs.fwd_ok = tiled_gather_configure(n, s.S, s.F, s.G, s.H, s.W, b, blur_k, bf16, &bs.tiled_fwd) &&
                         tiled_gather_configure(n, s.F, s.S, s.G, s.H, s.W, b, blur_k, bf16, &bs.tiled_dx);
@@ -402,12 +442,17 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
             bs.dense3_ok = bs.dense_ok && b == 4 && DAU_TUNE_INT("DAU_DENSE_R3", 1) != 0 &&
                            r3::dense_gather_configure(n, s.S, s.F, s.G, s.H, s.W, 3, blur_k, bf16, &bs.dense3_fwd) &&
                            r3::dense_gather_configure(n, s.F, s.S, s.G, s.H, s.W, 3, blur_k, bf16, &bs.dense3_dx);
-            bs.split3_ok = want_split && bs.fwd_ok && b == 4 &&
-                           s3::split_gather_configure(n, s.S, s.F, s.G, s.H, s.W, 3, blur_k, bf16, &bs.split3_fwd) &&
-                           s3::split_gather_configure(n, s.F, s.S, s.G, s.H, s.W, 3, blur_k, bf16, &bs.split3_dx);
             size_t need = 0;
             if (bs.fwd_ok) need = std::max(tiled_gather_workspace_bytes(bs.tiled_fwd), tiled_gather_workspace_bytes(bs.tiled_dx));
-            if (bs.split3_ok) need = std::max(need, std::max(s3::split_gather_workspace_bytes(bs.split3_fwd), s3::split_gather_workspace_bytes(bs.split3_dx)));
+            for (int r = 2; r <= 4; ++r) {
+                bool& ok = bs.split_ok[r - 2];
+                const int g_live = s.G - desc->number_units_ignore;
+                ok = split_allowed && bs.fwd_ok && b == 4 &&
+                     (split_forced || (split_pays(r, s.S, s.F, g_live, s.H, s.W) && split_pays(r, s.F, s.S, g_live, s.H, s.W))) &&
+                     kSplit[r - 2].configure(n, s.S, s.F, s.G, s.H, s.W, r, blur_k, bf16, &bs.split_fwd[r - 2]) &&
+                     kSplit[r - 2].configure(n, s.F, s.S, s.G, s.H, s.W, r, blur_k, bf16, &bs.split_dx[r - 2]);
+                if (ok) need = std::max(need, std::max(kSplit[r - 2].workspace_bytes(bs.split_fwd[r - 2]), kSplit[r - 2].workspace_bytes(bs.split_dx[r - 2])));
+            }
             if (bs.dense_ok) need = std::max(need, std::max(r4::dense_gather_workspace_bytes(bs.dense_fwd), r4::dense_gather_workspace_bytes(bs.dense_dx)));
             if (bs.dense3_ok) need = std::max(need, std::max(r3::dense_gather_workspace_bytes(bs.dense3_fwd), r3::dense_gather_workspace_bytes(bs.dense3_dx)));
             return need;
@@ -445,9 +490,9 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
         delete p;
         return fail(DAU_INVALID_ARGUMENT, "DAU_FLAG_DENSE_BF16 needs DAU_FLAG_IO_BF16 (it is the bf16 layer's gather-sum)");
     }
-    if ((desc->flags & DAU_FLAG_DENSE_SPLIT_F16) && (desc->flags & DAU_FLAG_DENSE_BF16)) {
+    if ((desc->flags & DAU_FLAG_DENSE_SPLIT_F16) && (desc->flags & (DAU_FLAG_DENSE_BF16 | DAU_FLAG_NO_DENSE_SPLIT))) {
         delete p;
-        return fail(DAU_INVALID_ARGUMENT, "DAU_FLAG_DENSE_SPLIT_F16 and DAU_FLAG_DENSE_BF16 exclude each other");
+        return fail(DAU_INVALID_ARGUMENT, "DAU_FLAG_DENSE_SPLIT_F16 excludes DAU_FLAG_DENSE_BF16 and DAU_FLAG_NO_DENSE_SPLIT");
     }
     if ((desc->flags & (DAU_FLAG_DENSE_WGRAD_NEVER | DAU_FLAG_DENSE_WGRAD_ALWAYS)) &&
         (!(desc->flags & DAU_FLAG_DENSE_BF16) || (desc->flags & DAU_FLAG_DENSE_WGRAD_NEVER && desc->flags & DAU_FLAG_DENSE_WGRAD_ALWAYS))) {
@@ -468,7 +513,7 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
     // dynamic bucket selection: tiled kernels, more than one bucket (or the two radii of the dense forms), not switched off (DAU_FLAG_STATIC_BUCKET; tuning build:
     // DAU_DYNAMIC_BUCKET=0 in the environment at plan creation).  The pinned status mirror needs a device; without one
     // (header-only checks on a CPU box) the plan simply has no hint.
-    p->dynamic = (p->nsets > 1 || p->sets[0].dense3_ok || p->sets[0].split3_ok) && !(desc->flags & DAU_FLAG_STATIC_BUCKET) && DAU_TUNE_INT("DAU_DYNAMIC_BUCKET", 1) != 0 &&
+    p->dynamic = (p->nsets > 1 || p->sets[0].dense3_ok || p->sets[0].any_split()) && !(desc->flags & DAU_FLAG_STATIC_BUCKET) && DAU_TUNE_INT("DAU_DYNAMIC_BUCKET", 1) != 0 &&
                  (p->algo_fwd == DAU_ALGO_TILED || p->algo_bwd == DAU_ALGO_TILED);
     void* hs = nullptr;
     if (hipHostMalloc(&hs, sizeof(HostStatus), hipHostMallocDefault) == hipSuccess && hs) {
@@ -540,7 +585,10 @@ int dau_conv_plan_get_info(const dau_conv_plan* plan, dau_conv_plan_info* info) 
     info->dot_region = plan->top().dot_ok ? plan->top().tiled_dot.region_cols * 100 + plan->top().tiled_dot.region_rows : 0;
     info->gather_fblock = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.fblock : 0;
     info->gather_variant = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.variant : -1;
-    info->gather_dense_split = (plan->sets[0].split3_ok && plan->dynamic && plan->algo_fwd == DAU_ALGO_TILED) ? 1 : 0;
+    info->gather_dense_split = 0;
+    if (plan->dynamic && plan->algo_fwd == DAU_ALGO_TILED)
+        for (int r = 2; r <= 4; ++r)
+            if (plan->sets[0].split_ok[r - 2]) info->gather_dense_split |= 1 << r;
     return DAU_OK;
 }
 
@@ -575,10 +623,10 @@ int dau_conv_forward(const dau_conv_plan* p, void* stream, const float* x, const
             for (int n0 = 0; n0 < s.N; n0 += bs.slab_gather) {             // one slab unless the staged copy exceeds the budget
                 const float* xs = slab_ptr(x, (size_t)n0 * s.S * s.H * s.W, esize);
                 float* ys = slab_ptr(y, (size_t)n0 * s.F * s.H * s.W, esize);
-                if (cand[ci].r3 && bs.split3_ok) {                         // offsets within +-3: two-limb f16 GEMM, fp32 accuracy
-                    s3::split_gather_prepare(st, bs.split3_fwd, xs, ws.filters, false, ws.table, ws.tiled, cand[ci].guard);
+                if (const int r = cand[ci].split_r) {                      // offsets within +-r: two-limb f16 GEMM, fp32 accuracy
+                    kSplit[r - 2].prepare(st, bs.split_fwd[r - 2], xs, ws.filters, false, ws.table, ws.tiled, cand[ci].guard);
                     ProfScope prof(p, 0, st);
-                    s3::split_gather_run(st, bs.split3_fwd, ys, ws.tiled, cand[ci].guard);
+                    kSplit[r - 2].run(st, bs.split_fwd[r - 2], ys, ws.tiled, cand[ci].guard);
                     continue;
                 }
                 if (cand[ci].r3) {                                         // bf16 layer, offsets within +-3: 7 x 7 dense kernel
@@ -703,10 +751,10 @@ int dau_conv_backward(const dau_conv_plan* p, void* stream, const float* x, cons
                 for (int n0 = 0; n0 < s.N; n0 += bs.slab_gather) {
                     const float* dys = slab_ptr(dy, (size_t)n0 * s.F * s.H * s.W, esize);
                     float* dxs = slab_ptr(dx, (size_t)n0 * s.S * s.H * s.W, esize);
-                    if (cand[ci].r3 && bs.split3_ok) {
-                        s3::split_gather_prepare(st, bs.split3_dx, dys, ws.filters, true, ws.table_t, ws.tiled_dx, cand[ci].guard);
+                    if (const int r = cand[ci].split_r) {
+                        kSplit[r - 2].prepare(st, bs.split_dx[r - 2], dys, ws.filters, true, ws.table_t, ws.tiled_dx, cand[ci].guard);
                         ProfScope prof(p, 1, st);
-                        s3::split_gather_run(st, bs.split3_dx, dxs, ws.tiled_dx, cand[ci].guard);
+                        kSplit[r - 2].run(st, bs.split_dx[r - 2], dxs, ws.tiled_dx, cand[ci].guard);
                         continue;
                     }
                     if (cand[ci].r3) {

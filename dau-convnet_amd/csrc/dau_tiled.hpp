@@ -65,7 +65,8 @@ DAU_DECLARE_DENSE_GATHER(r4)
 DAU_DECLARE_DENSE_GATHER(r3)
 
 // Densified gather-sum at fp32 accuracy (k_dense_split.hip): the same dense form with both operands split into two binary16
-// limbs, three f16 MFMAs per tap -- fp32 or bf16 activations, inside the fp32 parity bar; namespace s3 = offsets within +-3.
+// limbs, three f16 MFMAs per tap -- fp32 or bf16 activations, inside the fp32 parity bar; the same source compiled once per
+// offset radius (Makefile): namespaces s2, s3, s4 = offsets within +-2, +-3, +-4 (5 x 5, 7 x 7, 9 x 9 taps).
 #define DAU_DECLARE_SPLIT_GATHER(NS)                                                                                           \
     namespace NS {                                                                                                            \
     bool split_gather_configure(int N, int Cin, int Cout, int G, int H, int W, int R, int blur_k, bool bf16, DenseConfig* cfg); \
@@ -75,7 +76,9 @@ DAU_DECLARE_DENSE_GATHER(r3)
                               const UnitRef* table, void* workspace, const Guard& guard);                                     \
     void split_gather_run(hipStream_t st, const DenseConfig& cfg, float* out, void* workspace, const Guard& guard);           \
     }
+DAU_DECLARE_SPLIT_GATHER(s2)
 DAU_DECLARE_SPLIT_GATHER(s3)
+DAU_DECLARE_SPLIT_GATHER(s4)
 
 struct TiledDotConfig {
     Shape sh;

@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
 
     issue(0, 0);
     f16x8 ah[kDK], al[kDK], an[2], bn[2];                   // A fragments (hi, lo) of a row of taps; the next row's first two
-    static_assert(kAhead == 2 && kDK >= 5, "the A ring below is written for two taps ahead");
+    static_assert(kAhead == 2 && kDK >= 5 && kDK <= 9, "the A ring below is written for two taps ahead");
 #pragma unroll
     for (int i = 0; i < kAhead; ++i) { ah[i] = wp[i * wtap]; al[i] = wp[i * wtap + wlo]; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -24,7 +24,8 @@ FLAG_STATIC_BUCKET = 1 << 5   # always the kernels of the bucket max_kernel_size
 FLAG_DENSE_BF16 = 1 << 6      # with FLAG_IO_BF16: gather-sum passes of calls with |mu| <= 4 as a densified bf16 MFMA GEMM
 FLAG_DENSE_WGRAD_NEVER = 1 << 7    # with FLAG_DENSE_BF16: parameter gradients always through the exact fp32 gather-dot
 FLAG_DENSE_WGRAD_ALWAYS = 1 << 8   # with FLAG_DENSE_BF16: dense parameter gradients from one unit per channel on (default: three)
-FLAG_DENSE_SPLIT_F16 = 1 << 9      # gather-sum passes of calls with |mu| <= 3 as a densified two-limb f16 MFMA GEMM at fp32 accuracy
+FLAG_DENSE_SPLIT_F16 = 1 << 9      # gather-sum passes of calls with |mu| <= 2 / 3 / 4 as a densified two-limb f16 MFMA GEMM at fp32 accuracy, whatever G
+FLAG_NO_DENSE_SPLIT = 1 << 10      # never (default: the radii that pay for the plan's unit count)
 
 ALGO_AUTO, ALGO_DIRECT, ALGO_TILED = 0, 1, 2
 PASS_FORWARD, PASS_BACKWARD = 1, 2

@@ -69,6 +69,11 @@ def _get_plan(x, w, settings):
             # calls whose offsets lie within +-4: the gather-sum passes (and, from three units on, the parameter gradients)
             # as densified bf16 MFMA GEMMs
             flags |= _capi.FLAG_DENSE_BF16
+    # the two-limb f16 dense gather-sum (fp32 accuracy): None = the library's choice (the radii that pay for this unit count)
+    if settings["dense_split"] is True and not (flags & _capi.FLAG_DENSE_BF16):
+        flags |= _capi.FLAG_DENSE_SPLIT_F16
+    elif settings["dense_split"] is False:
+        flags |= _capi.FLAG_NO_DENSE_SPLIT
     key = (N, S, F, G, H, W, settings["kernel_size"], settings["number_units_ignore"], flags, settings["algo"],
            _capi.filter_support(settings["sigma_hint"]), float(settings["mu_learning_rate_factor"]), x.device.index)
     plan = _PLANS.get(key)
@@ -114,7 +119,7 @@ def _settings(sigma, number_units_x=2, number_units_y=2, number_units_ignore=0, 
               sigma_iteration_step=1, component_border_bound=1.0, sigma_lower_bound=0.3, merge_iteration_step=0,
               merge_threshold=1, unit_testing=False, mu_learning_rate_factor=1.0, single_dim_kernel=False,
               forbid_positive_dim1=False, use_interpolation=True, sigma_hint=None, check_offsets="async",
-              algo=_capi.ALGO_AUTO, dense_bf16=False, process_group=None, grad_reduce="mean", name=None):
+              algo=_capi.ALGO_AUTO, dense_bf16=False, dense_split=None, process_group=None, grad_reduce="mean", name=None):
     if not unit_normalization or square_unit_normalization:
         raise _capi.InvalidArgumentError("only unit_normalization=True, square_unit_normalization=False is implemented")
     if sigma_hint is None:
@@ -128,7 +133,8 @@ def _settings(sigma, number_units_x=2, number_units_y=2, number_units_ignore=0, 
                 stride=int(stride), unit_testing=bool(unit_testing), mu_learning_rate_factor=float(mu_learning_rate_factor),
                 single_dim_kernel=bool(single_dim_kernel), forbid_positive_dim1=bool(forbid_positive_dim1),
                 use_interpolation=bool(use_interpolation), sigma_hint=float(sigma_hint),
-                check_offsets=mode, algo=int(algo), dense_bf16=bool(dense_bf16), process_group=process_group,
+                check_offsets=mode, algo=int(algo), dense_bf16=bool(dense_bf16),
+                dense_split=(None if dense_split is None else bool(dense_split)), process_group=process_group,
                 grad_reduce=grad_reduce)
 
 
@@ -316,7 +322,7 @@ class _DAUConvolution2d(object):
                  num_dau_units_ignore=0, mu_learning_rate_factor=500, dau_unit_border_bound=0.01,
                  dau_unit_sigma_bound=0.01, dau_unit_single_dim=False, dau_aggregation_forbid_positive_dim1=False,
                  dau_mu_interpolation=True, unit_testing=False, name=None, check_offsets="async", algo=_capi.ALGO_AUTO,
-                 dense_bf16=False, process_group=None, grad_reduce="mean"):
+                 dense_bf16=False, process_group=None, grad_reduce="mean", dense_split=None):
         if len(input_shape) != 4:
             raise ValueError("Only two dimensional DAUConv supported (rank-4 NCHW input).")
         if data_format is None or data_format == "NHWC":
@@ -343,6 +349,7 @@ class _DAUConvolution2d(object):
         self.check_offsets = check_offsets
         self.algo = algo
         self.dense_bf16 = dense_bf16
+        self.dense_split = dense_split
         self.process_group = process_group
         self.grad_reduce = grad_reduce
         self.mean_max_allowed_offset = float(np.floor(self.max_kernel_size / 2.0) - self.dau_unit_border_bound)
@@ -361,8 +368,8 @@ class _DAUConvolution2d(object):
                         forbid_positive_dim1=self.dau_aggregation_forbid_positive_dim1,
                         use_interpolation=self.dau_mu_interpolation, unit_testing=self.unit_testing,
                         sigma_hint=sigma_hint, check_offsets=self.check_offsets, algo=self.algo,
-                        dense_bf16=self.dense_bf16, process_group=self.process_group, grad_reduce=self.grad_reduce,
-                        name=self.name)
+                        dense_bf16=self.dense_bf16, dense_split=self.dense_split, process_group=self.process_group,
+                        grad_reduce=self.grad_reduce, name=self.name)
 
 
 class DAUConv2d(nn.Module):
@@ -372,7 +379,10 @@ class DAUConv2d(nn.Module):
     preconditions (NaN, |mu| beyond the kernel; dau_conv_op.cpp:250-262) are enforced -- "async" (default): read the
     previous call's on-device result from pinned host memory before each call, no stall, errors surface one call late
     (`dau_conv.check_pending_offsets()` flushes); True: wait for every call and raise at once, as the reference does;
-    False: never read the result back.  `dense_bf16=True` (bfloat16 inputs only): calls whose offsets lie within +-4 run
+    False: never read the result back.  `dense_split` (None: the library's choice, True: always, False: never): calls whose
+    offsets lie within +-2 / +-3 / +-4 run their two gather-sum passes as a densified GEMM on the f16 matrix cores with both
+    operands split into two binary16 limbs -- fp32 accuracy (the exact kernels' parity bar), about 1.7x faster at four units per
+    channel pair; by default a plan holds the radii that pay for its unit count.  `dense_bf16=True` (bfloat16 inputs only): calls whose offsets lie within +-4 run
     their forward and input-gradient passes as a densified bf16 matrix-core GEMM (DAU_FLAG_DENSE_BF16: taps and blurred
     activations rounded to bf16, fp32 sums) and, from three units per channel on, their
     parameter gradients as dense cross-correlations on the same cores -- the whole step about 2x faster than the exact
@@ -396,7 +406,7 @@ class DAUConv2d(nn.Module):
                  bias_constraint=None, trainable=True, mu_learning_rate_factor=500, dau_unit_border_bound=0.01,
                  dau_unit_single_dim=False, dau_aggregation_forbid_positive_dim1=False, dau_sigma_trainable=False,
                  dau_mu_interpolation=True, unit_testing=False, name=None, in_channels=None, check_offsets="async",
-                 algo=_capi.ALGO_AUTO, dense_bf16=False, process_group=None, grad_reduce="mean", **kwargs):
+                 algo=_capi.ALGO_AUTO, dense_bf16=False, process_group=None, grad_reduce="mean", dense_split=None, **kwargs):
         super(DAUConv2d, self).__init__()
         self.rank = 2
         self.filters = int(filters)
@@ -446,6 +456,7 @@ class DAUConv2d(nn.Module):
         self.check_offsets = check_offsets
         self.algo = algo
         self.dense_bf16 = dense_bf16
+        self.dense_split = dense_split
         self.process_group = process_group
         self.grad_reduce = grad_reduce
         # odd number of units: add one dummy (zero weight, ignored) unit (dau_conv.py:317-329)
@@ -533,7 +544,7 @@ class DAUConv2d(nn.Module):
             dau_aggregation_forbid_positive_dim1=self.dau_aggregation_forbid_positive_dim1,
             dau_mu_interpolation=self.dau_mu_interpolation, unit_testing=self.unit_testing, data_format="NCHW",
             name=self.name, check_offsets=self.check_offsets, algo=self.algo, dense_bf16=self.dense_bf16,
-            process_group=self.process_group, grad_reduce=self.grad_reduce)
+            process_group=self.process_group, grad_reduce=self.grad_reduce, dense_split=self.dense_split)
         self.built = True
 
     def _var(self, key):

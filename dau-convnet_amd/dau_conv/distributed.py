@@ -47,6 +47,9 @@ class OverlappedBackward(object):
         self.group = group
         self._work = None
         self._finalize = None
+        # measure_exposed(True): event pairs around the join in wait() -- the time the compute stream stands still for the
+        # exchange after the dx pass has been enqueued (what of the all-reduce is NOT hidden); read with exposed_ms()
+        self._events = None
 
     def run(self, sums_fn, dx_fn, finalize_fn):
         sums_fn(self.sums)
@@ -55,10 +58,32 @@ class OverlappedBackward(object):
         self._finalize = finalize_fn
         return dx_fn() if dx_fn is not None else None
 
+    def measure_exposed(self, on=True):
+        self._events = [] if on else None
+
+    def exposed_ms(self):
+        """(total ms, joins) the compute stream waited in wait() since measure_exposed(True); synchronizes the recorded events."""
+        if not self._events:
+            return 0.0, 0
+        total = 0.0
+        for a, b in self._events:
+            b.synchronize()
+            total += a.elapsed_time(b)
+        n = len(self._events)
+        self._events = []
+        return total, n
+
     def wait(self):
         """Make the current stream wait for the exchange, then finalize: returns (dw, dmu1, dmu2, dsigma)."""
         if self._work is not None:
-            self._work.wait()
+            if self._events is not None and self.sums.is_cuda:
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                self._work.wait()
+                b.record()
+                self._events.append((a, b))
+            else:
+                self._work.wait()
             self._work = None
         fin, self._finalize = self._finalize, None
         return fin(self.sums)

@@ -120,13 +120,17 @@ enum {
                                                parameter gradients whatever the unit count                   */
     DAU_FLAG_DENSE_WGRAD_ALWAYS = 1 << 8,   /* with DAU_FLAG_DENSE_BF16: dense parameter gradients from ONE unit
                                                per channel on (default: from three, where they start to pay) */
-    DAU_FLAG_DENSE_SPLIT_F16 = 1 << 9,      /* calls whose offsets lie within +-3 run their two gather-sum passes (y, dx) as the
-                                               densified 7x7 implicit GEMM on the f16 matrix cores with BOTH operands split
-                                               into two binary16 limbs (hi + lo, 22 significant bits; products hi*hi + lo*hi +
-                                               hi*lo, fp32 sums): fp32 accuracy -- the same parity bar as the exact gather -- at
-                                               3 * 49 / 16 of the fp32 rate per (pixel, channel pair) instead of 4 G.  float32
-                                               or bfloat16 activations; every other call, and the parameter gradients, keep the
-                                               exact kernels (k_dense_split.hip).  Excludes DAU_FLAG_DENSE_BF16.            */
+    DAU_FLAG_DENSE_SPLIT_F16 = 1 << 9,      /* The two gather-sum passes (y, dx) of calls whose offsets lie within +-2 / +-3 / +-4 can run
+                                               as a DENSIFIED 5x5 / 7x7 / 9x9 implicit GEMM on the f16 matrix cores with BOTH operands
+                                               split into two binary16 limbs (hi + lo, 22 significant bits; products hi*hi + lo*hi +
+                                               hi*lo, fp32 sums, k_dense_split.hip): fp32 accuracy -- the same parity bar as the exact
+                                               gather, measured margins in profiles/ -- at 3 * taps / 16 of the fp32 rate per (pixel,
+                                               channel pair) instead of 4 G.  float32 or bfloat16 activations; the call's offsets decide
+                                               on the device which member runs; every other call, and the parameter gradients, keep the
+                                               exact kernels.  DEFAULT (neither flag): the members that pay for the plan's unit count
+                                               (radius 2 from two units per channel pair, radius 3 from three, radius 4 from five).
+                                               This flag: all three members whatever the unit count.                        */
+    DAU_FLAG_NO_DENSE_SPLIT = 1 << 10,      /* never: always the exact fp32 gather (excludes DAU_FLAG_DENSE_SPLIT_F16)      */
     DAU_FLAG_DEFAULT = DAU_FLAG_USE_INTERPOLATION
 };
 
@@ -192,7 +196,8 @@ typedef struct dau_conv_plan_info {
     int32_t gather_fblock;     /* tiled gather-sum y pass of the static bucket: output channels per
                                   workgroup (4, 8, 12, 16; 0: direct)                             */
     int32_t gather_variant;    /* ... and the row of its kernel table (k_gather_mfma.hip kVariants) */
-    int32_t gather_dense_split; /* 1: calls within +-3 run the gather-sum passes as the two-limb f16 GEMM (DAU_FLAG_DENSE_SPLIT_F16) */
+    int32_t gather_dense_split; /* bit r (r = 2, 3, 4): calls whose offsets lie within +-r can run their gather-sum passes as the
+                                   two-limb f16 GEMM of that radius (0: never) */
 } dau_conv_plan_info;
 
 DAU_API int dau_conv_abi_version(void);

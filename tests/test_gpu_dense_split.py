@@ -1,6 +1,7 @@
-"""GPU: the densified gather-sum with two-limb f16 operands (DAU_FLAG_DENSE_SPLIT_F16, k_dense_split.hip): for calls whose
-offsets lie within +-3 the two gather-sum passes (y and dx) run as an implicit GEMM on the f16 matrix cores over a dense 7 x 7
-kernel per channel pair, every operand split into hi + lo binary16 limbs.  Bar: the FP32 one (north star: 1e-4 relative + the
+"""GPU: the densified gather-sum with two-limb f16 operands (k_dense_split.hip; DAU_FLAG_DENSE_SPLIT_F16 forces it, by default a
+plan holds the radii that pay for its unit count): for calls whose offsets lie within +-2 / +-3 / +-4 the two gather-sum passes
+(y and dx) run as an implicit GEMM on the f16 matrix cores over a dense 5 x 5 / 7 x 7 / 9 x 9 kernel per channel pair, every
+operand split into hi + lo binary16 limbs.  Bar: the FP32 one (north star: 1e-4 relative + the
 1e-6 floor of SURVEY.md 8d against the oracle) -- the form claims fp32 accuracy, so it gets no bar of its own; the measured
 distances go to gpurun_out/parity_margins.jsonl (kept under profiles/ per round).  Replaces the same reference code as the
 exact gather (dau_conv_forward_core.hpp:804-1605; tolerance of the reference's own test: dau_conv_test.py:300-333)."""
@@ -33,45 +34,73 @@ def _check(got, want, name):
 
 
 @pytest.mark.parametrize("shape", [
-    dict(N=2, S=16, F=128, G=4, H=56, W=56),      # one column block of 7 subtiles, whole chunks and channel blocks
-    dict(N=3, S=20, F=40, G=3, H=30, W=45),       # ragged everything: channels, rows, columns, odd batch
-    dict(N=2, S=7, F=5, G=2, H=9, W=6),           # tiny
+    dict(N=2, S=16, F=128, G=4, H=56, W=56),      # column blocks of four and of three tiles, whole chunks and channel blocks
+    dict(N=3, S=20, F=40, G=3, H=30, W=45),       # ragged everything: channels, rows, columns, odd batch; blocks of 3 + 3
+    dict(N=2, S=7, F=5, G=2, H=9, W=6),           # tiny: one block of one tile
     dict(N=2, S=33, F=130, G=6, H=28, W=28),      # two channel blocks, the second almost empty
-    dict(N=1, S=16, F=16, G=2, H=20, W=130),      # three column blocks
-    dict(N=2, S=32, F=64, G=1, H=17, W=64),       # eight subtiles per block
-    dict(N=4, S=24, F=32, G=5, H=14, W=14),       # two subtiles
+    dict(N=1, S=16, F=16, G=2, H=20, W=130),      # seventeen tiles: one block of five... of 4, 4, 3, 3, 3
+    dict(N=2, S=32, F=64, G=1, H=17, W=64),       # two blocks of four
+    dict(N=4, S=24, F=32, G=5, H=14, W=14),       # one block of two
     dict(N=2, S=8, F=8, G=4, H=27, W=27),         # odd width: the staging kernel's scalar loads
 ])
-def test_split_gather_against_oracle(shape):
+@pytest.mark.parametrize("radius", [2, 3, 4])
+def test_split_gather_against_oracle(shape, radius):
     N, S, F, G, H, W = (shape[q] for q in ("N", "S", "F", "G", "H", "W"))
-    x, dy, w, mu1, mu2 = make_inputs(43, N, S, F, G, H, W, 9, 3.0)
-    mu1.flat[0] = 3.0; mu2.flat[0] = -3.0; mu1.flat[1] = -3.0; mu2.flat[1] = 3.0     # the corners of the 7 x 7 kernel (and the +4 tap of weight 0 it leaves out)
+    r = float(radius)
+    x, dy, w, mu1, mu2 = make_inputs(43 + radius, N, S, F, G, H, W, 9, r)
+    # the corners of the (2r+1)^2 kernel (and the +r+1 tap of weight 0 it leaves out); radius 4: the layer's clip, 3.99
+    c = min(r, 3.99)
+    mu1.flat[0] = c; mu2.flat[0] = -c; mu1.flat[1] = -c; mu2.flat[1] = c
+    assert max(np.abs(mu1).max(), np.abs(mu2).max()) > radius - 1       # this call belongs to the member of THIS radius
     plan = _plan(N, S, F, G, H, W)
-    assert plan.info["gather_dense_split"] == 1
+    assert plan.info["gather_dense_split"] == 0b11100
     got = run_plan(plan, x, dy, w, mu1, mu2)
-    _check(got, _oracle(x, dy, w, mu1, mu2), "split/%dx%d" % (H, W))
+    _check(got, _oracle(x, dy, w, mu1, mu2), "split/r%d/%dx%d" % (radius, H, W))
 
 
-def test_split_gather_hands_over_to_the_exact_kernels_beyond_radius_three():
-    """One offset at 3.5: the call's device guard sends it to the exact bucket-4 gather (bit-identical to a plan without the
-    flag); back within +-3 the split form runs again.  Which arithmetic a call gets depends on its own offsets only."""
+@pytest.mark.parametrize("case", [
+    # (S, F, G, H, W) -> the radii a default plan holds: those that pay for the unit count on this tiling (split_pays, dau_conv_api.hip)
+    ((256, 256, 4, 56, 56), 0b01100), ((256, 256, 6, 56, 56), 0b11100), ((256, 256, 2, 56, 56), 0b00100),
+    ((256, 256, 1, 56, 56), 0), ((96, 256, 4, 27, 27), 0b00100), ((512, 512, 4, 28, 28), 0b01100), ((7, 5, 4, 16, 16), 0),
+])
+def test_default_plans_hold_the_radii_that_pay(case):
+    from dau_conv import _capi
+    (S, F, G, H, W), want = case
+    plan = _capi.Plan(2, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5)
+    assert plan.info["gather_dense_split"] == want, bin(plan.info["gather_dense_split"])
+    never = _capi.Plan(2, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=_capi.FLAG_USE_INTERPOLATION | _capi.FLAG_NO_DENSE_SPLIT)
+    assert never.info["gather_dense_split"] == 0
+    with pytest.raises(_capi.InvalidArgumentError):
+        _capi.Plan(2, S, F, G, H, W, flags=_capi.FLAG_USE_INTERPOLATION | _capi.FLAG_NO_DENSE_SPLIT | _capi.FLAG_DENSE_SPLIT_F16)
+
+
+def test_split_members_and_the_exact_kernels_share_a_plan():
+    """A kernel-17 plan: offsets within +-2, +-3, +-4 take the dense members of those radii, an offset of 5 the exact bucket-8
+    gather (bit-identical to a plan that has no dense member) -- decided per call on the device from the call's own offsets, so a
+    result never depends on what the plan saw before."""
     from dau_conv import _capi
     N, S, F, G, H, W = 2, 16, 32, 4, 24, 24
-    x, dy, w, mu1, mu2 = make_inputs(7, N, S, F, G, H, W, 9, 3.0)
-    plan = _plan(N, S, F, G, H, W)
-    ref = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=_capi.FLAG_USE_INTERPOLATION)
-    inside = run_plan(plan, x, dy, w, mu1, mu2)
-    exact_inside = run_plan(ref, x, dy, w, mu1, mu2)
-    assert not np.array_equal(inside["y"], exact_inside["y"])          # another arithmetic ...
-    _check(inside, _oracle(x, dy, w, mu1, mu2), "split/inside")        # ... inside the same bar
-    mu1b = mu1.copy(); mu1b.flat[5] = 3.5
-    outside = run_plan(plan, x, dy, w, mu1b, mu2)
-    exact = run_plan(ref, x, dy, w, mu1b, mu2)
-    for key in ("y", "dx"):
-        assert np.array_equal(outside[key], exact[key]), key
-    again = run_plan(plan, x, dy, w, mu1, mu2)
-    for key in ("y", "dx"):
-        assert np.array_equal(again[key], inside[key]), key
+    plan = _plan(N, S, F, G, H, W, k=17)
+    ref = _capi.Plan(N, S, F, G, H, W, max_kernel_size=17, sigma_hint=0.5, flags=_capi.FLAG_USE_INTERPOLATION | _capi.FLAG_NO_DENSE_SPLIT)
+    assert plan.info["gather_dense_split"] == 0b11100 and ref.info["gather_dense_split"] == 0
+    first = {}
+    for rnd in range(2):
+        for m in (2.0, 5.0, 3.0, 3.99):
+            x, dy, w, mu1, mu2 = make_inputs(7, N, S, F, G, H, W, 17, m)
+            mu1.flat[3] = m
+            got = run_plan(plan, x, dy, w, mu1, mu2)
+            exact = run_plan(ref, x, dy, w, mu1, mu2)
+            if m > 4:
+                for key in ("y", "dx"):
+                    assert np.array_equal(got[key], exact[key]), (m, key)
+            else:
+                assert not np.array_equal(got["y"], exact["y"])                 # another arithmetic ...
+                _check(got, _oracle(x, dy, w, mu1, mu2), "split/k17/m%g" % m)    # ... inside the same bar
+            if rnd == 0:
+                first[m] = got
+            else:
+                for key in ("y", "dx"):
+                    assert np.array_equal(got[key], first[m][key]), (m, key)
 
 
 @pytest.mark.parametrize("scale", [1e-6, 1.0, 3e4])
@@ -119,7 +148,7 @@ def test_split_gather_flags_and_dtypes(io):
         dy = torch.from_numpy(dy).to(torch.bfloat16).float().numpy()
     extra = (_capi.FLAG_IO_BF16 if bf else 0) | _capi.FLAG_UNIT_TESTING
     plan = _plan(N, S, F, G, H, W, extra=extra, number_units_ignore=1, sigma_hint=0.8)
-    assert plan.info["gather_dense_split"] == 1
+    assert plan.info["gather_dense_split"] == 0b11100
     got = run_plan(plan, x, dy, w, mu1, mu2, dtype=torch.bfloat16 if bf else None, sigma=0.8)
     want = _oracle(x, dy, w, mu1, mu2, sigma=0.8, ignore=1, unit_testing=True)
     if bf:     # y, dx are stored as bfloat16: the bf16 storage bar for those two, fp32 for the parameter gradients
@@ -131,22 +160,38 @@ def test_split_gather_flags_and_dtypes(io):
         _check(got, want, "split/flags")
 
 
-def test_split_gather_at_north_star_depth():
-    """S = F = 256, 56 x 56, G = 4 -- the depth (12 544 dense products x 3 limb pairs per output) of the headline workload, on 8
-    images: y and dx against the oracle at the fp32 bar, the margin recorded."""
-    N, S, F, G, H, W = 8, 256, 256, 4, 56, 56
-    x, dy, w, mu1, mu2 = make_inputs(2024, N, S, F, G, H, W, 9, 3.0)
-    plan = _plan(N, S, F, G, H, W)
+def _gather_passes(plan, x, dy, w, mu1, mu2):
+    from dau_conv import _capi
     dev = lambda a: torch.from_numpy(a).cuda()
+    S, G, F = w.shape[1:]
     sg = torch.full((1, S, G, F), 0.5, device="cuda")
     y = plan.forward(dev(x), dev(w), dev(mu1), dev(mu2), sg)
     plan.check_status()
-    from dau_conv import _capi
     dx = plan.backward(dev(x), dev(dy), dev(w), dev(mu1), dev(mu2), sg, need_mask=_capi.NEED_DX)[0]
     plan.check_status()
-    got = dict(y=y.cpu().numpy(), dx=dx.cpu().numpy())
+    return dict(y=y.cpu().numpy(), dx=dx.cpu().numpy())
+
+
+@pytest.mark.parametrize("cfg", [
+    # name, (N, S, F, G, H, W), offsets within: the depth of the BASELINE workloads on a few images, DEFAULT plans (no flag)
+    ("ns-depth N=8 S=F=256 56x56 G=4 r3", (8, 256, 256, 4, 56, 56), 3.0),
+    ("ns-depth N=4 S=F=256 56x56 G=4 r2", (4, 256, 256, 4, 56, 56), 2.0),
+    ("c2-depth N=4 S=F=256 56x56 G=6 r4", (4, 256, 256, 6, 56, 56), 3.99),
+    ("c3-depth N=8 S=F=512 28x28 G=4 r3", (8, 512, 512, 4, 28, 28), 3.0),
+    ("c1 N=64 96->256 27x27 G=4 r3", (64, 96, 256, 4, 27, 27), 3.0),
+])
+def test_split_gather_at_baseline_depth(cfg):
+    """y and dx at the depth (input channels x taps x 3 limb pairs per output) of the BASELINE workloads against the oracle at the
+    fp32 bar, through the plan a caller gets by default; the margins go on record."""
+    from dau_conv import _capi
+    name, (N, S, F, G, H, W), m = cfg
+    x, dy, w, mu1, mu2 = make_inputs(2024, N, S, F, G, H, W, 9, m)
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5)
+    radius = 2 if m <= 2 else 3 if m <= 3 else 4
+    assert plan.info["gather_dense_split"] & (1 << radius), "the default plan of this workload holds the radius-%d member" % radius
+    got = _gather_passes(plan, x, dy, w, mu1, mu2)
     want = dict(y=orc.forward(x, w, mu1, mu2, 0.5), dx=orc.backward(x, dy, w, mu1, mu2, 0.5, need=("dx",))["dx"])
+    mg = record_margins("split/" + name, got, want, "1e-4 rel + 1e-6 max-norm (fp32 bar)")
+    print("margins", name, mg)
     for key in ("y", "dx"):
-        assert_parity(got[key], want[key], "split/ns-depth/" + key)
-    m = record_margins("split/ns-depth N=8 S=F=256 56x56 G=4", got, want, "1e-4 rel + 1e-6 max-norm (fp32 bar)")
-    print("margins", m)
+        assert_parity(got[key], want[key], "split/%s/%s" % (name, key))

@@ -126,3 +126,52 @@ def test_random_configuration_dense_bf16(seed):
     for t, key in zip(got[1:], ("dw", "dmu1", "dmu2", "dsigma")):
         if dense_params: assert_parity(t.cpu().numpy(), want[key], tag + key, rel=2e-2, floor=1e-2)
         else: assert_parity(t.cpu().numpy(), want[key], tag + key)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DAU_FUZZ_SPLIT_SEEDS", "60"))))
+def test_random_configuration_dense_split(seed):
+    """The same sweep with DAU_FLAG_DENSE_SPLIT_F16 (all three dense members whatever the unit count; offsets within +-4 under
+    kernels 9 and 17; float32 and bfloat16 activations): every tensor at the FP32 bar -- the two-limb f16 form claims fp32
+    accuracy -- except y / dx stored as bfloat16 (the storage bar of test_gpu_bf16.py)."""
+    from dau_conv import _capi
+    c = _config(seed)
+    rs = np.random.RandomState(9000 + seed)
+    N, S, F, G, H, W = (c[q] for q in ("N", "S", "F", "G", "H", "W"))
+    k = 9 if seed % 3 else 17
+    bf = seed % 4 == 3
+    x = rs.rand(N, S, H, W).astype(np.float32)
+    dy = rs.randn(N, F, H, W).astype(np.float32)
+    if seed % 5 == 0:
+        dy *= np.float32(1e-7)                     # gradients of a loss-scaled-away magnitude: binary16 alone would flush them
+    if bf:
+        x = torch.from_numpy(x).to(torch.bfloat16).float().numpy(); dy = torch.from_numpy(dy).to(torch.bfloat16).float().numpy()
+    w = (rs.randn(1, S, G, F) * 0.1).astype(np.float32)
+    m = min(c["m"], 4.0) if seed % 2 else min(c["m"], float(rs.choice([2.0, 3.0])))
+    mu1 = np.clip(rs.uniform(-m, m, (1, S, G, F)), -3.99, 3.99).astype(np.float32)
+    mu2 = np.clip(rs.uniform(-m, m, (1, S, G, F)), -3.99, 3.99).astype(np.float32)
+    if c["flags"]["single_dim_kernel"]:
+        mu2[:] = 0.0
+    fl = _capi.FLAG_DENSE_SPLIT_F16 | (_capi.FLAG_IO_BF16 if bf else 0)
+    if c["flags"]["use_interpolation"]: fl |= _capi.FLAG_USE_INTERPOLATION
+    if c["flags"]["single_dim_kernel"]: fl |= _capi.FLAG_SINGLE_DIM_KERNEL
+    if c["flags"]["forbid_positive_dim1"]: fl |= _capi.FLAG_FORBID_POSITIVE_DIM1
+    if c["unit_testing"]: fl |= _capi.FLAG_UNIT_TESTING
+    sigma = c["sigma"] if c["sigma"] <= 1.0 else 0.5           # supports up to 11 taps have a staging instantiation
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=k, number_units_ignore=c["ignore"], flags=fl, sigma_hint=sigma)
+    assert plan.info["gather_dense_split"] == 0b11100
+    dev = lambda a: torch.from_numpy(a).cuda()
+    dt = torch.bfloat16 if bf else torch.float32
+    sig = torch.full((1, S, G, F), sigma, device="cuda")
+    for _ in range(2):                                  # kernel 17: the second round has a hint
+        y = plan.forward(dev(x).to(dt), dev(w), dev(mu1), dev(mu2), sig)
+        got = plan.backward(dev(x).to(dt), dev(dy).to(dt), dev(w), dev(mu1), dev(mu2), sig)
+        plan.check_status()
+    kw = dict(ignore=c["ignore"], **c["flags"])
+    want_y = orc.forward(x, w, mu1, mu2, sigma, **kw)
+    want = orc.backward(x, dy, w, mu1, mu2, sigma, unit_testing=c["unit_testing"], **kw)
+    tag = "split seed%d %s " % (seed, {q: c[q] for q in ("N", "S", "F", "G", "H", "W", "ignore")})
+    bar = dict(rel=2e-2, floor=4e-3) if bf else {}
+    assert_parity(y.float().cpu().numpy(), want_y, tag + "y", **bar)
+    assert_parity(got[0].float().cpu().numpy(), want["dx"], tag + "dx", **bar)
+    for t, key in zip(got[1:], ("dw", "dmu1", "dmu2", "dsigma")):
+        assert_parity(t.cpu().numpy(), want[key], tag + key)
