@@ -572,12 +572,14 @@ void dispatch_dense(int nsub, int ft, hipStream_t st, const DenseArgs* a, int gr
         }
         return;
     }
+#ifdef DAU_TUNING                 // the four-wave form (DAU_DENSE_FT=2) is a tuning alternative: not instantiated in the release build
     switch (nsub) {
         case 2: launch_dense<2, 2>(st, a, grid); break;
         case 4: launch_dense<4, 2>(st, a, grid); break;
         case 7: launch_dense<7, 2>(st, a, grid); break;
         default: launch_dense<8, 2>(st, a, grid); break;
     }
+#endif
 }
 
 void stage_tile(const DenseConfig& c, const DenseGeom& g, int* TR, int* TC, size_t* lds) {

@@ -25,13 +25,18 @@
 //    8x8 region) items with the LDS error tile filled by global_load_lds (two tiles for bucket 4, one for bucket 8).
 //    Buckets beyond 8 run as offset-window passes over a WORK LIST of half-sweeps (dot_worklist_kernel below).
 //    Work is split in chunks over the items; a small deterministic pass sums the partials (no float atomics).
-//  * Accuracy: a lane's fp32 accumulators take at most ~1024 products; then they are added, in DOUBLE, to the workgroup's own
-//    slot of the partial sums (kFlushTerms below) and start again from zero.  The rounding error of a parameter gradient --
+//  * Accuracy: a lane's fp32 accumulators take at most ~1024 products; then they are added to the workgroup's own slot of the
+//    partial sums (kFlushTerms below) and start again from zero.  The slot is a float where it takes at most 16 such additions
+//    per chunk (round 4: half the flush traffic; the chunks are summed in double) and a double otherwise (512 x 512 maps).  The rounding error of a parameter gradient --
 //    a sum of N*H*W signed products -- therefore does not grow with the batch, the map size or the chunking: 6-7e-7 of the
 //    max-norm at every size measured (before: 1.4e-6 at 4 x 512 x 512; the floor of SURVEY.md 8d is 1e-6).  Cost at the
 //    north-star shape, same box: 17.17 ms without, 17.34 ms with a flush every 1024 products, 17.62 ms every 512 (4.5e-7).
 //  Tuning knobs (timing experiments only): -DDAU_DOT_WAVES=8, DAU_DOT_NBUF=1, DAU_DOT_AS1, DAU_DOT_DEBUG.
 #include <cstdlib>
+#include <algorithm>
+#ifndef DAU_DOT_FLUSH_TERMS
+#define DAU_DOT_FLUSH_TERMS 1024      // products per fp32 accumulator chain (see "Accuracy" above)
+#endif
 #include <type_traits>
 #include <utility>
 
@@ -560,15 +565,18 @@ __global__ void __launch_bounds__(1024) dot_worklist_kernel(const UnitRef* __res
 // the others by a pass with slabs1 (u = (s*G + g)*F + f)
 // zero_from: units g >= zero_from have no partial sums (binned passes give ignored units no slot): their sums are zero
 // accumulate: add to r4 (second and later batch slabs of a call) instead of overwriting it
-__global__ void dot_reduce_kernel(const double* __restrict__ partial, long n, int G, int F, int g_split, int slabs0,
+// partial_f32: the slabs hold float sums (see DotArgs::partial_f32), else double
+__global__ void dot_reduce_kernel(const void* __restrict__ partial, int partial_f32, long n, int G, int F, int g_split, int slabs0,
                                   int slabs1, int zero_from, int accumulate, float* __restrict__ r4, const Guard guard) {
     if (!guard_pass(guard)) return;
+    const double* pd = static_cast<const double*>(partial);
+    const float* pf = static_cast<const float*>(partial);
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int g = (int)((i / F) % G);
         const int slabs = g < g_split ? slabs0 : slabs1;
         double s = 0.0;
         if (g < zero_from)
-            for (int c = 0; c < slabs; ++c) s += partial[(long)c * n + i];
+            for (int c = 0; c < slabs; ++c) s += partial_f32 ? (double)pf[(long)c * n + i] : pd[(long)c * n + i];
         r4[i] = accumulate ? (float)((double)r4[i] + s) : (float)s;
     }
 }
@@ -580,7 +588,10 @@ struct DotArgs {
     const char* ep;
     const float* xk;
     const float* params;
-    double* partial;            // [chunk][4][S][G][F]: every (chunk, unit) belongs to exactly one workgroup, which accumulates into it
+    void* partial;              // [chunk][4][S][G][F]: every (chunk, unit) belongs to exactly one workgroup, which accumulates into it
+    int partial_f32;            // the slots are float: a slot takes at most kMaxF32Flushes additions of ~1024-product sums, which
+                                // costs nothing measurable in accuracy (the chunks are summed in double) and halves the flush
+                                // traffic; chunks with more flushes per slot (512 x 512 maps) keep double slots
     int N, S, F, G, R;
     int g_begin;                // first unit of this pass
     int NP, nfb, nsb, ngb, nbuf, chunks, items;   // window passes (work list): nsb = channel groups, ngb = rounds allocated
@@ -884,9 +895,6 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     // partial[chunk][k][(s*G+g)*F+f] += image 0 + image 1.  Every unit is written by exactly one workgroup per chunk: its own
     // (unit block) pass, or -- BINNED -- the pass of the one (window, half-sweep) it was dealt into; so these are additions by
     // ONE lane in program order (deterministic).  The first flush stores.
-#ifndef DAU_DOT_FLUSH_TERMS
-#define DAU_DOT_FLUSH_TERMS 1024
-#endif
     constexpr int kFlushTerms = DAU_DOT_FLUSH_TERMS;
     constexpr int kFlushItems = kFlushTerms / (RH * RW) > 0 ? kFlushTerms / (RH * RW) : 1;
     const long units = (long)a.S * a.G * a.F;
@@ -905,15 +913,25 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
                     u = __float_as_int(a.params[(((((((long)sub * a.nfb + fb) * a.nsb + sb) * a.rmax + gb) * kDWaves + wave) * AS + si) * 64 + lane) * kParamDwords + 5]);
                 asm volatile("" : "+v"(u));
                 if (BINNED ? u >= 0 : (s < a.S && g < a.G && f < a.F)) {
-                    double* dst = a.partial + (long)chunk * kNumK * units + u;
+                    // the first flush stores; the later ones add with the hardware's atomic (no return value: nothing to wait
+                    // for -- a load / add / store round trip per entry cost 0.8 ms of the 17 ms north-star pass).  The slot belongs
+                    // to this lane alone, so the order of the additions is the program's.
+                    if (a.partial_f32) {
+                        float* dst = static_cast<float*>(a.partial) + (long)chunk * kNumK * units + u;
 #pragma unroll
-                    for (int kk = 0; kk < kNumK; ++kk) {
-                        const double v = (double)acc[si][gp][0][kk] + (double)acc[si][gp][1][kk];
-                        // the first flush stores; the later ones add with the hardware's fp64 atomic (no return value: nothing to
-                        // wait for -- a load / add / store round trip per entry cost 0.8 ms of the 17 ms north-star pass).
-                        // The slot belongs to this lane alone, so the order of the additions is the program's.
-                        if (flushed) unsafeAtomicAdd(&dst[kk * units], v);
-                        else dst[kk * units] = v;
+                        for (int kk = 0; kk < kNumK; ++kk) {
+                            const float v = acc[si][gp][0][kk] + acc[si][gp][1][kk];
+                            if (flushed) unsafeAtomicAdd(&dst[kk * units], v);
+                            else dst[kk * units] = v;
+                        }
+                    } else {
+                        double* dst = static_cast<double*>(a.partial) + (long)chunk * kNumK * units + u;
+#pragma unroll
+                        for (int kk = 0; kk < kNumK; ++kk) {
+                            const double v = (double)acc[si][gp][0][kk] + (double)acc[si][gp][1][kk];
+                            if (flushed) unsafeAtomicAdd(&dst[kk * units], v);
+                            else dst[kk * units] = v;
+                        }
                     }
                 }
                 acc[si][gp][0] = f4{0, 0, 0, 0}; acc[si][gp][1] = f4{0, 0, 0, 0};
@@ -1419,7 +1437,7 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
     DotArgs a{};
     a.ep = ws + l.ep_off;
     a.xk = reinterpret_cast<const float*>(ws + l.xk_off);
-    a.partial = reinterpret_cast<double*>(ws + l.partial_off);
+    a.partial = ws + l.partial_off;
     a.N = s.N; a.S = s.S; a.F = s.F; a.G = s.G; a.R = g.Rp;
     a.NP = c.NP; a.nfb = g.nfb; a.nbuf = g.nbuf; a.Rt = g.Rt; a.nsub1 = g.nsub1; a.chunks = g.chunks; a.items = g.items;
     a.rx = g.rx; a.ry = g.ry; a.EX = g.EX; a.EY = g.EY; a.Hp = g.Hp; a.Wp = g.Wp; a.epitch = g.epitch; a.erows = g.erows;
@@ -1431,6 +1449,17 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
     a.guard = guard;
     const bool binned = g.nsub1 > 1;
     const size_t lds = (size_t)g.nbuf * g.tile_bytes;
+    {
+        // float slots where a slot takes few additions (DotArgs::partial_f32): flushes per (chunk, slot) of the busiest pass
+        constexpr int kMaxF32Flushes = 16;
+        const int flush_items = std::max(1, DAU_DOT_FLUSH_TERMS / (g.RH * g.RW));
+        int flushes = 0;
+        for (int i = 0; i < g.npass; ++i) {
+            const int per = (g.items + g.pass[i].chunks - 1) / g.pass[i].chunks;
+            flushes = std::max(flushes, (per + flush_items - 1) / flush_items);
+        }
+        a.partial_f32 = (flushes <= kMaxF32Flushes && DAU_TUNE_INT("DAU_DOT_PARTIAL_F32", 1) != 0) ? 1 : 0;
+    }
     for (int i = 0; i < g.npass; ++i) {           // every pass writes its own units' slabs of the partial sums
         const DotGeometry::Pass& ps = g.pass[i];
         a.params = reinterpret_cast<const float*>(ws + l.params_off + ps.params_off);
@@ -1442,7 +1471,7 @@ void tiled_dot_run(hipStream_t st, const TiledDotConfig& c, float* r4, void* wor
     const long n = (long)kNumK * s.S * s.G * s.F;
     const int rgrid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     const int g_split = g.npass == 2 ? g.pass[1].g_begin : s.G;
-    hipLaunchKernelGGL(dot_reduce_kernel, dim3(rgrid), dim3(256), 0, st, a.partial, n, s.G, s.F, g_split,
+    hipLaunchKernelGGL(dot_reduce_kernel, dim3(rgrid), dim3(256), 0, st, (const void*)a.partial, a.partial_f32, n, s.G, s.F, g_split,
                        g.pass[0].chunks, g.pass[g.npass - 1].chunks, binned ? s.G - c.ignore : s.G, accumulate ? 1 : 0, r4, guard);
 }
 

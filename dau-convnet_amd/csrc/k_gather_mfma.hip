@@ -149,6 +149,9 @@ Geometry make_geometry(int H, int W, int R, int G, int N, int Cout, int only = -
     for (int i = 0; i < (int)(sizeof(kVariants) / sizeof(kVariants[0])); ++i) {
         const Variant& v = kVariants[i];
         if (only >= 0 && i != only) continue;
+#ifndef DAU_TUNING
+        if (v.tuning) continue;                                                       // not instantiated in the release build
+#endif
         if (only < 0 && v.tuning == 2) continue;                                      // explicit request only
         if (only < 0 && v.tuning && v.split != want_split) continue;
         int ph, pw, cols, rows;
@@ -799,7 +802,9 @@ void dispatch_variant(int variant, hipStream_t st, const GatherArgs* a, int grid
         case 4: launch_variant<GatherTraits<3, 3, 40, true, 1>>(st, a, grid, lds); break;
         case 5: launch_variant<GatherTraits<1, 1, 40, true, 1>>(st, a, grid, lds); break;
         case 6: launch_variant<GatherTraits<4, 4, 40, false, 1>>(st, a, grid, lds); break;
+#ifdef DAU_TUNING
         case 7: launch_variant<GatherTraits<7, 7, 72, true, 3>>(st, a, grid, lds); break;
+#endif
         case 8: launch_variant<GatherTraits<4, 4, 72, true, 2, 2, 26624>>(st, a, grid, lds); break;
         case 9: launch_variant<GatherTraits<3, 3, 40, true, 2, 4, 13312>>(st, a, grid, lds); break;
         case 10: launch_variant<GatherTraits<2, 2, 40, true, 1, 4, 10240, 8>>(st, a, grid, lds); break;
@@ -811,15 +816,21 @@ void dispatch_variant(int variant, hipStream_t st, const GatherArgs* a, int grid
         case 16: launch_variant<GatherTraits<4, 4, 72, false, 2>>(st, a, grid, lds); break;
         case 17: launch_variant<GatherTraits<4, 4, 104, false, 1, 1, 0, 8>>(st, a, grid, lds); break;
         case 18: launch_variant<GatherTraits<4, 4, 40, false, 1, 1, 0, 8>>(st, a, grid, lds); break;
+#ifdef DAU_TUNING
         case 19: launch_variant<GatherTraits<4, 4, 40, false, 2, 2, 13312, 4>>(st, a, grid, lds); break;
+#endif
+#ifdef DAU_TUNING
         case 20: launch_variant<GatherTraits<7, 7, 72, true, 2, 1, 0, 4, 3>>(st, a, grid, lds); break;
+#endif
         case 21: launch_variant<GatherTraits<4, 4, 40, false, 1, 1, 0, 12>>(st, a, grid, lds); break;
         case 22: launch_variant<GatherTraits<4, 4, 104, false, 1, 1, 0, 12>>(st, a, grid, lds); break;
         case 23: launch_variant<GatherTraits<4, 4, 72, false, 1, 1, 0, 12>>(st, a, grid, lds); break;
+#ifdef DAU_TUNING                // explicit-request rows (Variant::tuning != 0) exist in the tuning build only
         case 24: launch_variant<GatherTraits<1, 15, 40, false, 1, 1, 0, 12, 2, 32>>(st, a, grid, lds); break;
         case 25: launch_variant<GatherTraits<1, 14, 40, false, 1, 1, 0, 12, 2, 32>>(st, a, grid, lds); break;
         case 26: launch_variant<GatherTraits<4, 4, 40, false, 1, 1, 0, 12, 3>>(st, a, grid, lds); break;
         case 27: launch_variant<GatherTraits<4, 4, 72, false, 1, 1, 0, 12, 3>>(st, a, grid, lds); break;
+#endif
         default: break;
     }
 }

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 I=0
 for SET in "$@"; do
   I=$((I+1))
-  rocprofv3 --pmc $SET --output-format csv -d gpurun_out/pmcc_${TAG}_$I -o p -- python3 bench.py --no-cpu-baseline --no-layer --steps 2 --warmup 1 $BARGS > gpurun_out/pmcc_${TAG}_$I.log 2>&1 || { tail -5 gpurun_out/pmcc_${TAG}_$I.log; exit 1; }
+  rocprofv3 --pmc $SET --output-format csv -d gpurun_out/pmcc_${TAG}_$I -o p -- python3 bench.py --no-cpu-baseline --no-layer --no-check --steps 2 --warmup 1 $BARGS > gpurun_out/pmcc_${TAG}_$I.log 2>&1 || { tail -5 gpurun_out/pmcc_${TAG}_$I.log; exit 1; }
 done
 python3 - "$TAG" <<'PY'
 import csv, glob, json, re, sys
@@ -16,7 +16,7 @@ acc = {}
 for f in glob.glob("gpurun_out/pmcc_%s_*/**/*counter_collection.csv" % tag, recursive=True):
     for r in csv.DictReader(open(f)):
         k = re.sub(r"^void ", "", r["Kernel_Name"]).replace("(anonymous namespace)::", "").split("(")[0]
-        if not (k.startswith("dau::gather") or k.startswith("dau::dense_gather") or "wg_gemm" in k):
+        if not (k.startswith("dau::gather") or "dense_gather" in k or "wg_gemm" in k or "split_gather" in k):
             continue
         d = acc.setdefault(k, {}).setdefault(r["Counter_Name"], [0.0, 0])
         d[0] += float(r["Counter_Value"]); d[1] += 1
