@@ -319,11 +319,14 @@ def main():
         torch.cuda.synchronize()
 
     parity = None
+    if args.check > 0:
+        # EVERY rank takes the gate's step (with more than one rank a step holds a collective: the ranks must agree on how many
+        # they run); rank 0 compares its shard with the oracle while the others wait at the fence below
+        y, dx = step()
+        torch.cuda.synchronize()
     if args.check > 0 and rank == 0:
         from oracle import dau_oracle as orc
         nchk = min(args.check, N)
-        y, dx = step()
-        torch.cuda.synchronize()
         xs, dys = x[:nchk].float().cpu().numpy(), dy[:nchk].float().cpu().numpy()
         wn, m1n, m2n = w.cpu().numpy(), mu1.cpu().numpy(), mu2.cpu().numpy()
         want_y = orc.forward(xs, wn, m1n, m2n, 0.5, ignore=ignore)
@@ -349,11 +352,17 @@ def main():
                 pv[key] = float((np.abs(got - wv) - (prel * np.abs(wv) + pfloor * np.abs(wv).max())).max())
             parity.update(param_channels=fs, param_violation=pv, param_rel=prel, param_floor=pfloor)
             parity["ok"] = bool(parity["ok"] and all(v <= 0 for v in pv.values()))
-        if not parity["ok"]:
-            raise SystemExit("bench.py --check: the HIP path differs from the oracle: %s" % parity)
         # the oracle's OpenMP team keeps spinning on the host cores for a moment after its last parallel region; the launches of
         # a millisecond-sized step right behind it were seen to take 5x as long (C1 dense: 5.2 instead of 1.0 ms per step)
         time.sleep(1.0)
+    if args.check > 0:
+        ok = 1 if (parity is None or parity["ok"]) else 0
+        if use_dist:           # every rank learns rank 0's verdict (a rank that left alone would hang the others' next collective)
+            t = torch.tensor([ok], device=dev, dtype=torch.int32)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t.item())
+        if not ok:
+            raise SystemExit("bench.py --check: the HIP path differs from the oracle: %s" % (parity,))
 
     for _ in range(args.warmup):
         step()
@@ -446,7 +455,9 @@ def main():
             # the pass ran in its densified form on the bf16 matrix cores: price the FLOPs that form executes (9 x 9 = 81 taps per
             # (input, output) channel pair and pixel; 324 for the four parameter-gradient kinds) against the bf16 roof
             # (offsets within +-3, as every BASELINE workload draws them, take the radius-3 members: 7 x 7 taps / displacements)
-            side = 7.0 if float(m) <= 3.0 else 9.0
+            r3_level = int(plan.info.get("dense_bf16_radius3", 0))      # which passes have a 7 x 7 member in THIS plan
+            has_r3 = r3_level >= (2 if dominant == "gather_dot" else 1)
+            side = 7.0 if (mu_max <= 3.0 and has_r3) else 9.0
             taps = side * side * ((3.0 if args.no_dsigma else 4.0) if dominant == "gather_dot" else 1.0)
             ach = 2.0 * taps * N * H * W * S * F / (kern[dominant]["avg_ms"] * 1e-3) / 1e12
             peak = BF16_PEAK_TFLOPS

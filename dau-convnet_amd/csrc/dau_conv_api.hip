@@ -202,10 +202,21 @@ struct Candidate {
     int split_r = 0;          // 2, 3, 4: the set's two-limb f16 dense member of that radius (sets[0], gather-sum passes only)
 };
 
+// dau_conv_last_status has just reported the whole mirror: forget it, sticky record included.
 void clear_host_status(const dau_conv_plan* p) {
     if (!p->host_status) return;
     volatile unsigned* h = reinterpret_cast<volatile unsigned*>(p->host_status);
     h[2] = 0u; h[1] = 0u; h[0] = 0u; h[4] = 0u; h[5] = 0u;
+}
+// dau_conv_check_status has just reported the status of ONE workspace's call: forget the "most recent call" part, and of the sticky
+// record only what is this very report (the same out-of-range maximum, the NaN flag if this call had one) -- it may also hold the
+// not-yet-reported error of another layer or stream that shares the plan, which dau_conv_last_status must still see.
+void clear_reported_status(const dau_conv_plan* p, unsigned max_bits, bool nan_seen) {
+    if (!p->host_status) return;
+    volatile unsigned* h = reinterpret_cast<volatile unsigned*>(p->host_status);
+    h[2] = 0u; h[1] = 0u; h[0] = 0u;
+    if (h[4] == max_bits) h[4] = 0u;
+    if (nan_seen) h[5] = 0u;
 }
 
 // pass_kind: 0 = gather-sum (needs fwd_ok), 1 = gather-dot (needs dot_ok)
@@ -516,7 +527,8 @@ int dau_conv_plan_create(const dau_conv_desc* desc, dau_conv_plan** plan_out) {
     p->dynamic = (p->nsets > 1 || p->sets[0].dense3_ok || p->sets[0].any_split()) && !(desc->flags & DAU_FLAG_STATIC_BUCKET) && DAU_TUNE_INT("DAU_DYNAMIC_BUCKET", 1) != 0 &&
                  (p->algo_fwd == DAU_ALGO_TILED || p->algo_bwd == DAU_ALGO_TILED);
     void* hs = nullptr;
-    if (hipHostMalloc(&hs, sizeof(HostStatus), hipHostMallocDefault) == hipSuccess && hs) {
+    // portable + mapped: a plan may be used on any device, and every device's prepare_units_kernel writes the mirror
+    if (hipHostMalloc(&hs, sizeof(HostStatus), hipHostMallocPortable | hipHostMallocMapped) == hipSuccess && hs) {
         std::memset(hs, 0, sizeof(HostStatus));
         p->host_status = static_cast<HostStatus*>(hs);
     } else {
@@ -585,6 +597,7 @@ int dau_conv_plan_get_info(const dau_conv_plan* plan, dau_conv_plan_info* info) 
     info->dot_region = plan->top().dot_ok ? plan->top().tiled_dot.region_cols * 100 + plan->top().tiled_dot.region_rows : 0;
     info->gather_fblock = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.fblock : 0;
     info->gather_variant = plan->algo_fwd == DAU_ALGO_TILED ? plan->top().tiled_fwd.variant : -1;
+    info->dense_bf16_radius3 = dense_reachable && plan->dynamic && plan->sets[0].dense3_ok ? (plan->sets[0].wgrad3_ok ? 2 : 1) : 0;
     info->gather_dense_split = 0;
     if (plan->dynamic && plan->algo_fwd == DAU_ALGO_TILED)
         for (int r = 2; r <= 4; ++r)
@@ -823,7 +836,7 @@ int dau_conv_check_status(const dau_conv_plan* p, void* stream, const void* work
     float mx;
     std::memcpy(&mx, &h.max_abs_mu_bits, sizeof(float));
     if (max_abs_mu_out) *max_abs_mu_out = mx;
-    if (h.nan_seen || mx > (float)p->bucket) clear_host_status(p);   // reported here: dau_conv_last_status stays quiet about it
+    if (h.nan_seen || mx > (float)p->bucket) clear_reported_status(p, h.max_abs_mu_bits, h.nan_seen != 0);   // reported here
     if (h.nan_seen) return fail(DAU_FAILED_PRECONDITION, "DAUConvOp ERROR: got NaN value in offset (mu1,mu2) variable");
     if (mx > (float)p->bucket)
         return fail(DAU_INVALID_ARGUMENT,

@@ -79,6 +79,9 @@ __global__ void prepare_units_kernel(const float* __restrict__ w, const float* _
                     h[0] = mx; h[1] = nn; h[2] = 1u;   // [2]: a completed call has reported
                     // a bad status is also recorded STICKY ([4] worst max|mu| beyond the bucket, [5] NaN seen): every later
                     // call of this plan overwrites [0..2], only the host's report clears [4..5]
+                    // (plain stores: calls of several streams / devices may race here and with the host's clear.  The NaN flag is
+                    // a store of 1; of two racing out-of-range maxima either may stay -- both lie beyond the bucket, so the error is
+                    // reported either way, only the number in its message may be the smaller one)
                     if (nn) h[5] = 1u;
                     if (mx > __float_as_uint((float)bucket) && mx > h[4]) h[4] = mx;
                 }

@@ -62,7 +62,7 @@ class _Desc(ctypes.Structure):
 class _Info(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in
                 ("offset_bucket", "blur_support", "algo_forward", "algo_backward", "drop_last_col", "drop_last_row",
-                 "gather_patch", "gather_stack", "dot_windows", "gather_windows", "bucket_sets", "gather_dense_bf16", "batch_slab_gather", "batch_slab_dot", "dot_region", "gather_fblock", "gather_variant", "gather_dense_split")]
+                 "gather_patch", "gather_stack", "dot_windows", "gather_windows", "bucket_sets", "gather_dense_bf16", "batch_slab_gather", "batch_slab_dot", "dot_region", "gather_fblock", "gather_variant", "dense_bf16_radius3", "gather_dense_split")]
 
 
 def _load():

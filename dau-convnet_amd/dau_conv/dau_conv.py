@@ -84,6 +84,14 @@ def _get_plan(x, w, settings):
                       number_units_ignore=settings["number_units_ignore"], flags=flags, algo=settings["algo"],
                       sigma_hint=settings["sigma_hint"], mu_learning_rate_factor=settings["mu_learning_rate_factor"],
                       device=x.device)
+    if settings["algo"] == _capi.ALGO_AUTO and _capi.ALGO_DIRECT in (plan.info["algo_forward"], plan.info["algo_backward"]):
+        # the LDS-tiled kernels refused this shape (e.g. more than 16 units per channel pair under a kernel larger than 17, a
+        # prefilter window or error row larger than the LDS): correct, but orders of magnitude slower -- say so once per plan
+        which = [n for n, a in (("forward / input gradient", plan.info["algo_forward"]), ("parameter gradients", plan.info["algo_backward"]))
+                 if a == _capi.ALGO_DIRECT]
+        warnings.warn("DAUConv: N=%d C=%d->%d %dx%d, %d units, max_kernel_size=%d: the %s run on the plain one-thread-per-output "
+                      "kernels (the tiled MFMA kernels do not support this shape); expect them to be orders of magnitude slower"
+                      % (N, S, F, H, W, G, settings["kernel_size"], " and the ".join(which)), RuntimeWarning, stacklevel=3)
     _PLANS[key] = plan
     while len(_PLANS) > _PLAN_CACHE_MAX:
         _, old = _PLANS.popitem(last=False)

@@ -196,6 +196,8 @@ typedef struct dau_conv_plan_info {
     int32_t gather_fblock;     /* tiled gather-sum y pass of the static bucket: output channels per
                                   workgroup (4, 8, 12, 16; 0: direct)                             */
     int32_t gather_variant;    /* ... and the row of its kernel table (k_gather_mfma.hip kVariants) */
+    int32_t dense_bf16_radius3; /* DAU_FLAG_DENSE_BF16 plans: 1 if calls within +-3 take the 7x7 members (gather-sum), 2 if the parameter
+                                   gradients do too (49 displacements); 0: the 9x9 members only */
     int32_t gather_dense_split; /* bit r (r = 2, 3, 4): calls whose offsets lie within +-r can run their gather-sum passes as the
                                    two-limb f16 GEMM of that radius (0: never) */
 } dau_conv_plan_info;

@@ -13,6 +13,7 @@
 
 #include <list>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 
@@ -141,11 +142,15 @@ hipStream_t StreamOf(tf::OpKernelContext* ctx) {
 // sigma enters a plan only through the prefilter support 2*ceil(5*sigma)+1, so the key holds the descriptor with sigma_hint
 // replaced by the smallest sigma of that support: a trainable sigma (new value every step) keeps hitting the same plan.  The
 // cache is bounded (least recently used plan dropped; an op sees a handful of shapes in its life).
+// Plans are handed out reference-counted: concurrent Session::Run calls or executor threads can run Compute of one kernel at the
+// same time, so a Compute may still be inside dau_conv_forward / dau_conv_check_status with a plan while another Compute's new
+// shape evicts it from the cache.  Eviction only drops the cache's reference; the plan (and its pinned status block) is destroyed
+// when the last Compute that holds it returns.
+using PlanRef = std::shared_ptr<dau_conv_plan>;
 class PlanCache {
   public:
     static constexpr size_t kMaxPlans = 16;
-    ~PlanCache() { for (auto& e : plans_) dau_conv_plan_destroy(e.second); }
-    int Get(const dau_conv_desc& d, dau_conv_plan** plan) {
+    int Get(const dau_conv_desc& d, PlanRef* plan) {
         dau_conv_desc canon = d;
         canon.sigma_hint = static_cast<float>(dau_conv_filter_support(d.sigma_hint));   // the support stands in for sigma
         const std::string key(reinterpret_cast<const char*>(&canon), sizeof(canon));
@@ -156,20 +161,17 @@ class PlanCache {
                 *plan = plans_.front().second;
                 return DAU_OK;
             }
-        const int rc = dau_conv_plan_create(&d, plan);
+        dau_conv_plan* raw = nullptr;
+        const int rc = dau_conv_plan_create(&d, &raw);
         if (rc != DAU_OK) return rc;
+        plan->reset(raw, [](dau_conv_plan* p) { dau_conv_plan_destroy(p); });
         plans_.emplace_front(key, *plan);
-        while (plans_.size() > kMaxPlans) {
-            // Compute checks every call's status synchronously (dau_conv_check_status), so a dropped plan has nothing pending;
-            // no other thread can still hold it: TF serialises the Compute calls of one op instance on its stream
-            dau_conv_plan_destroy(plans_.back().second);
-            plans_.pop_back();
-        }
+        while (plans_.size() > kMaxPlans) plans_.pop_back();                             // drops the cache's reference only
         return DAU_OK;
     }
   private:
     std::mutex mu_;
-    std::list<std::pair<std::string, dau_conv_plan*>> plans_;
+    std::list<std::pair<std::string, PlanRef>> plans_;
 };
 
 class DAUConvOp : public tf::OpKernel {
@@ -180,8 +182,9 @@ class DAUConvOp : public tf::OpKernel {
         OP_REQUIRES(ctx, x.dims() == 4 && w.dims() == 4, tf::errors::InvalidArgument("input and parameters must have rank 4"));
         hipStream_t st = StreamOf(ctx);
         const dau_conv_desc d = attrs_.Describe(x, w, HostSigma(sigma, st));
-        dau_conv_plan* plan = nullptr;
-        OP_REQUIRES_OK(ctx, ToStatus(plans_.Get(d, &plan)));
+        PlanRef held;                                            // keeps the plan alive for the whole call (see PlanCache)
+        OP_REQUIRES_OK(ctx, ToStatus(plans_.Get(d, &held)));
+        dau_conv_plan* plan = held.get();
         tf::Tensor* y = nullptr;
         OP_REQUIRES_OK(ctx, ctx->allocate_output(0, tf::TensorShape({d.batch, d.out_channels, d.height, d.width}), &y));
         size_t ws_bytes = 0;
@@ -207,8 +210,9 @@ class DAUConvGradOp : public tf::OpKernel {
                          &sigma = ctx->input(5);
         hipStream_t st = StreamOf(ctx);
         const dau_conv_desc d = attrs_.Describe(x, w, HostSigma(sigma, st));
-        dau_conv_plan* plan = nullptr;
-        OP_REQUIRES_OK(ctx, ToStatus(plans_.Get(d, &plan)));
+        PlanRef held;                                            // keeps the plan alive for the whole call (see PlanCache)
+        OP_REQUIRES_OK(ctx, ToStatus(plans_.Get(d, &held)));
+        dau_conv_plan* plan = held.get();
         tf::Tensor* out[5];
         for (int i = 0; i < 5; ++i) OP_REQUIRES_OK(ctx, ctx->allocate_output(i, ctx->input(i + 1).shape(), &out[i]));
         size_t ws_bytes = 0;

@@ -178,7 +178,7 @@ def _gather_passes(plan, x, dy, w, mu1, mu2):
     ("ns-depth N=4 S=F=256 56x56 G=4 r2", (4, 256, 256, 4, 56, 56), 2.0),
     ("c2-depth N=4 S=F=256 56x56 G=6 r4", (4, 256, 256, 6, 56, 56), 3.99),
     ("c3-depth N=8 S=F=512 28x28 G=4 r3", (8, 512, 512, 4, 28, 28), 3.0),
-    ("c1 N=64 96->256 27x27 G=4 r3", (64, 96, 256, 4, 27, 27), 3.0),
+    ("c1 N=64 96->256 27x27 G=4 r2", (64, 96, 256, 4, 27, 27), 2.0),      # (radius 3 does not pay on this tiling: 27 -> 32, 96 -> 128)
 ])
 def test_split_gather_at_baseline_depth(cfg):
     """y and dx at the depth (input channels x taps x 3 limb pairs per output) of the BASELINE workloads against the oracle at the
