@@ -125,15 +125,17 @@ const SplitFns kSplit[3] = {
 };
 // Does the dense form of radius r pay against the exact gather?  MFMA work per pass in fp32-rate MAC units: the dense GEMM runs
 // (2r+1)^2 taps x 3 limb products at 16x the fp32 rate over the PADDED tile (8-row / 8-column blocks, 128 output channels, 16 input
-// channels) plus its staging, at ~55 % of the f16 roof; the exact gather 4 MACs per live unit at ~60 % of the fp32 roof (measured
-// at the north-star shape: 5.2 + 0.5 ms against 8.9 ms at radius 3, four units).  Radius 2 pays from two units per channel pair on
-// whole tiles, radius 3 from three, radius 4 from five.
+// channels) plus its staging, at ~55 % of the f16 roof; the exact gather 4 MACs per live unit at ~60 % of the fp32 roof on maps
+// of 32 pixels and more, ~45 % on smaller ones (measured, same box, gather + staging per pass against the exact gather: NS radius 3
+// 5.4 + 0.5 against 8.9 ms at four units, radius 4 8.5 + 0.5 against 9.4; radius 2 2.9 + 0.5 against 5.4 at two units; C1 27 x 27
+// radius 3 0.36 / 0.42 + 0.07 against 0.60 / 0.51).  On whole tiles radius 2 pays from two units per channel pair on, radius 3 from
+// three, radius 4 from four.
 bool split_pays(int r, int Cin, int Cout, int G_live, int H, int W) {
     const double taps = (2.0 * r + 1) * (2.0 * r + 1);
     const double hp = (H + 7) / 8 * 8, wp = (W + 7) / 8 * 8, fp = (Cout + 127) / 128 * 128, sp = (Cin + 15) / 16 * 16;
     const double dense = hp * wp * (fp * sp * taps * 3.0 / 16.0 / 0.55 + sp * 430.0);
-    const double exact = (double)H * W * Cout * Cin * G_live * 4.0 / 0.60;
-    return dense < 0.9 * exact;
+    const double exact = (double)H * W * Cout * Cin * G_live * 4.0 / ((H < 32 || W < 32) ? 0.45 : 0.60);
+    return dense < 1.1 * exact;
 }
 
 struct dau_conv_plan {

@@ -862,6 +862,19 @@ __global__ void __launch_bounds__(kDWaves * 64) __attribute__((amdgpu_waves_per_
     // slot t of the sweep that starts at `base`
     // (window passes: `base` is the sweep origin in the channel group's first plane, voff the lane's channel + position offset)
     auto x_fetch = [&](f2& dst, const char* base, int t, unsigned voff) {
+#ifdef DAU_DIAG_FUSED_XK
+        // Timing experiment (tools/build_variant.sh ... -DDAU_DIAG_FUSED_XK; DESIGN "the fused prefilter"): a LOWER BOUND of what
+        // computing the four derivative-filtered kinds inside this kernel would add.  One Xk load stands for 16 positions x 4 kinds x
+        // an image pair of one input channel; from raw x that is, per position, three 7-tap horizontal passes (shared by the seven rows
+        // that use them: 21 packed FMAs) and five 7-tap vertical passes (35) = 56 packed FMAs, i.e. 14 wave instructions per load
+        // with the work spread perfectly over the 64 lanes -- no loads of raw x, no LDS exchange, no borders, no registers.
+        {
+            f2 d_ = dst;
+#pragma unroll
+            for (int q_ = 0; q_ < 14; ++q_) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(d_));
+            asm volatile("" ::"v"(d_));
+        }
+#endif
         if constexpr (BINNED) x_load(dst, voff, base + (size_t)(t / 4) * 4 * xpitch + (t % 4) * 64, 0);   // column pair t % 4 of row block t / 4
         else if constexpr (RW == 8) x_load(dst, xlane, base + 2 * t * xpitch, 0);
         else x_load(dst, xoff[t], base, 0);

@@ -128,7 +128,7 @@ enum {
                                                channel pair) instead of 4 G.  float32 or bfloat16 activations; the call's offsets decide
                                                on the device which member runs; every other call, and the parameter gradients, keep the
                                                exact kernels.  DEFAULT (neither flag): the members that pay for the plan's unit count
-                                               (radius 2 from two units per channel pair, radius 3 from three, radius 4 from five).
+                                               (on whole tiles: radius 2 from two units per channel pair, radius 3 from three, radius 4 from four).
                                                This flag: all three members whatever the unit count.                        */
     DAU_FLAG_NO_DENSE_SPLIT = 1 << 10,      /* never: always the exact fp32 gather (excludes DAU_FLAG_DENSE_SPLIT_F16)      */
     DAU_FLAG_DEFAULT = DAU_FLAG_USE_INTERPOLATION

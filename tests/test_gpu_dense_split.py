@@ -60,8 +60,8 @@ def test_split_gather_against_oracle(shape, radius):
 
 @pytest.mark.parametrize("case", [
     # (S, F, G, H, W) -> the radii a default plan holds: those that pay for the unit count on this tiling (split_pays, dau_conv_api.hip)
-    ((256, 256, 4, 56, 56), 0b01100), ((256, 256, 6, 56, 56), 0b11100), ((256, 256, 2, 56, 56), 0b00100),
-    ((256, 256, 1, 56, 56), 0), ((96, 256, 4, 27, 27), 0b00100), ((512, 512, 4, 28, 28), 0b01100), ((7, 5, 4, 16, 16), 0),
+    ((256, 256, 4, 56, 56), 0b11100), ((256, 256, 6, 56, 56), 0b11100), ((256, 256, 2, 56, 56), 0b00100),
+    ((256, 256, 1, 56, 56), 0), ((96, 256, 4, 27, 27), 0b01100), ((512, 512, 4, 28, 28), 0b11100), ((7, 5, 4, 16, 16), 0),
 ])
 def test_default_plans_hold_the_radii_that_pay(case):
     from dau_conv import _capi
@@ -178,7 +178,7 @@ def _gather_passes(plan, x, dy, w, mu1, mu2):
     ("ns-depth N=4 S=F=256 56x56 G=4 r2", (4, 256, 256, 4, 56, 56), 2.0),
     ("c2-depth N=4 S=F=256 56x56 G=6 r4", (4, 256, 256, 6, 56, 56), 3.99),
     ("c3-depth N=8 S=F=512 28x28 G=4 r3", (8, 512, 512, 4, 28, 28), 3.0),
-    ("c1 N=64 96->256 27x27 G=4 r2", (64, 96, 256, 4, 27, 27), 2.0),      # (radius 3 does not pay on this tiling: 27 -> 32, 96 -> 128)
+    ("c1 N=64 96->256 27x27 G=4 r3", (64, 96, 256, 4, 27, 27), 3.0),
 ])
 def test_split_gather_at_baseline_depth(cfg):
     """y and dx at the depth (input channels x taps x 3 limb pairs per output) of the BASELINE workloads against the oracle at the
