@@ -173,26 +173,26 @@ def lib_fingerprint():
     return _capi.build_id()
 
 
-def measured_traffic(workload_key, io, dominant):
+def measured_traffic(workload_key, io, dominant, split_r=0):
     """HBM bytes per pass of the dominant kernel from the committed rocprofv3 --pmc passes of THIS command
-    (tools/pmc_traffic.sh writes profiles/r3_pmc_traffic.json: counters cannot be read from inside the process).  Only
+    (tools/pmc_traffic.sh writes profiles/r4_pmc_traffic.json: counters cannot be read from inside the process).  Only
     used when that file was taken for this workload with this very build of the library; otherwise null + the reason."""
-    path = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r4_pmc_traffic.json")
     try:
         pmc = json.load(open(path))
     except Exception:
-        return None, "no PMC pass committed for this build (profiles/r3_pmc_traffic.json missing)"
+        return None, "no PMC pass committed for this build (profiles/r4_pmc_traffic.json missing)"
     run = pmc.get("runs", {}).get("%s/%s" % (workload_key, io))
     if run is None:
         return None, "no PMC pass committed for workload %s/%s" % (workload_key, io)
     if run.get("src_sha256_16") != lib_fingerprint():
         return None, "committed PMC pass is from another build of the library (stale)"
-    key = {"gather_dot": "dau::gather_dot_kernel", "gather_sum_fwd": "dau::gather_mfma_kernel",
-           "gather_sum_dx": "dau::gather_mfma_kernel"}.get(dominant, "")
+    gather = "dau::s%d::split_gather_kernel" % split_r if split_r else "dau::gather_mfma_kernel"
+    key = {"gather_dot": "dau::gather_dot_kernel", "gather_sum_fwd": gather, "gather_sum_dx": gather}.get(dominant, "")
     fam = run["kernels"].get(key)       # the family entry: all instantiations / window launches of one pass
     if not fam or "hbm_bytes_per_pass" not in fam:
         return None, "dominant kernel not in the committed PMC pass"
-    return round(fam["hbm_bytes_per_pass"] / 1e9, 3), "profiles/r3_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, separate passes)"
+    return round(fam["hbm_bytes_per_pass"] / 1e9, 3), "profiles/r4_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, separate passes)"
 
 
 def main():
@@ -447,7 +447,7 @@ def main():
     dominant = max(kern, key=lambda n: kern[n]["avg_ms"]) if kern else None
     roofline = None
     if dominant:
-        traffic, traffic_note = measured_traffic(wl_key, args.io, dominant)
+        traffic, traffic_note = measured_traffic(wl_key, args.io, dominant, split_r)
         ach = flops[dominant] / (kern[dominant]["avg_ms"] * 1e-3) / 1e12
         peak, roof_note = FP32_PEAK_TFLOPS, None
         dense_level = int(plan.info.get("gather_dense_bf16", 0)) if dense else 0

@@ -1,13 +1,13 @@
 #!/bin/bash
 # HBM traffic per kernel from PMC counters: two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), no trace
 # domains, as /opt/skills/guides/MI355X_MICROARCH.md prescribes.  Writes gpurun_out/<tag>_pmc_traffic.json in the format
-# bench.py reads from profiles/r3_pmc_traffic.json (merge the "runs" entries there and commit).
+# bench.py reads from profiles/r4_pmc_traffic.json (merge the "runs" entries there and commit).
 # usage (on the GPU box, from the repo root): tools/pmc_traffic.sh <tag> <workload> <io> [more bench args...]
 TAG=$1; WL=$2; IO=$3; shift 3
 STEPS=3; WARM=1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmc_${TAG}_$C -o $C -- python3 bench.py --no-cpu-baseline --no-layer --steps $STEPS --warmup $WARM --workload $WL --io $IO "$@" > gpurun_out/pmc_${TAG}_$C.log 2>&1 || { tail -5 gpurun_out/pmc_${TAG}_$C.log; exit 1; }
+  rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmc_${TAG}_$C -o $C -- python3 bench.py --no-cpu-baseline --no-layer --no-check --steps $STEPS --warmup $WARM --workload $WL --io $IO "$@" > gpurun_out/pmc_${TAG}_$C.log 2>&1 || { tail -5 gpurun_out/pmc_${TAG}_$C.log; exit 1; }
 done
 python3 - "$TAG" "$WL" "$IO" "$STEPS" "$WARM" "$*" <<'PY'
 import csv, glob, hashlib, json, re, sys
@@ -34,7 +34,9 @@ for k, v in acc.items():
     family = k.split("<")[0]
     fam[family] = fam.get(family, 0.0) + per_step
 # per PASS of the dominant kernels: the step runs two gather-sum passes (forward, dx) and one gather-dot pass
-for family, passes in (("dau::gather_mfma_kernel", 2), ("dau::gather_dot_kernel", 1)):
+# (a guarded member that does not run is dispatched too: a few KB; the family a call really takes carries the bytes)
+for family, passes in (("dau::gather_mfma_kernel", 2), ("dau::gather_dot_kernel", 1), ("dau::s2::split_gather_kernel", 2),
+                       ("dau::s3::split_gather_kernel", 2), ("dau::s4::split_gather_kernel", 2)):
     if family in fam:
         kern[family] = dict(hbm_bytes_per_pass=fam[family] / passes, passes_per_step=passes)
 sys.path.insert(0, ".")
