@@ -416,7 +416,19 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int fw = wave & 3, pw = wave >> 2;                 // channel part / row half of the workgroup tile
-    int t = blockIdx.x;
+    // Workgroups are dealt to the eight XCDs round robin (block b runs on XCD b % 8) and every XCD has its own L2: consecutive
+    // LOGICAL ids -- the channel blocks of one window, then the next column block, the next row block (both share halo with it),
+    // the same image -- are mapped to one XCD, so that a window is fetched from HBM once, not once per channel block
+    int t;
+#ifdef DAU_SPLIT_NO_XCD_MAP                // (timing experiment: tools/build_variant.sh)
+    t = blockIdx.x;
+#else
+    {
+        const int nblk = gridDim.x, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+        const int per = nblk / 8, rem = nblk % 8;
+        t = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + idx;
+    }
+#endif
     const int fb = t % (a.CoutP / kDFB); t /= (a.CoutP / kDFB);       // channel blocks fastest: they share the window
     const int cb = t % a.ncb; t /= a.ncb;
     const int rb = t % a.nrb;
