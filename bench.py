@@ -557,7 +557,7 @@ def main():
                                (" [offsets: %s instead of U(-m,m)]" % args.offsets if args.offsets != "uniform" else "") +
                                (" [gather-sum passes%s as densified bf16 MFMA GEMM]" % (" and parameter gradients" if dense and int(plan.info.get("gather_dense_bf16", 0)) == 2 else "") if dense else "") +
                                (" [gather-sum passes: two-limb f16 dense GEMM of radius %d, fp32 accuracy; max|mu| = %.2f]" % (split_r, mu_max) if split_r else
-                                (" [gather-sum passes: exact fp32 gather; max|mu| = %.2f]" % mu_max)) +
+                                ("" if dense else " [gather-sum passes: exact fp32 gather; max|mu| = %.2f]" % mu_max)) +
                                (" [SIDE LINE: the step does not ask for dsigma (dx, dw, dmu1, dmu2 only)]" if args.no_dsigma else "") +
                                (" [one step captured into a HIP graph, replays timed]" if args.graph and not use_dist else "") +
                                ("" if backend == "nccl" else " [REHEARSAL: %s backend, ranks share GPUs]" % backend),
