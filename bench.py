@@ -546,6 +546,11 @@ def main():
                    steps=args.steps, warmup=args.warmup, ms_per_step=round(elapsed / args.steps * 1e3, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None,
                    dtype=args.io, accumulate="f32", data="synthetic",
+                   arithmetic=dict(gather_sum=("bf16 products (opt-in dense form), f32 sums" if dense else
+                                               "two binary16 limbs per operand (22 significant bits; hi*hi + lo*hi + hi*lo on the f16 matrix cores), f32 sums: "
+                                               "fp32 accuracy, gated at the fp32 bar" if split_r else "f32 (v_mfma_f32_4x4x1)"),
+                                   gather_dot=("bf16 products (opt-in dense form), f32 sums" if dense and int(plan.info.get("gather_dense_bf16", 0)) == 2
+                                               else "f32 (packed FMA + v_mfma_f32_4x4x1), partial sums float/double")),
                    ranks_seen=(dist.get_world_size() if use_dist else 1),
                    comm=(dict(backend=("rccl" if backend == "nccl" else backend), communicator_size=dist.get_world_size(),
                               exchange="all_reduce(sum) of raw param-grad sums [4,S,G,F] = %d floats per step, async under the dx pass; finalize after"
