@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import dau_oracle as orc
-from util import assert_parity, make_inputs, record_margins, run_plan
+from util import assert_parity, case_kernel_size, golden_cases, load_case, make_inputs, record_margins, run_plan
 
 pytestmark = pytest.mark.gpu
 
@@ -101,6 +101,30 @@ def test_split_members_and_the_exact_kernels_share_a_plan():
             else:
                 for key in ("y", "dx"):
                     assert np.array_equal(got[key], first[m][key]), (m, key)
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_vectors_through_the_dense_members(name):
+    """The golden cases of the reference's own numpy oracle (tests/golden: arrays the reference class returned) whose offsets lie
+    within +-4, with the dense members forced: forward + all five gradients at the bar of the golden test of test_gpu_parity.py
+    (the files carry the numpy oracle's float32 accumulation error: floor 3e-6)."""
+    from dau_conv import _capi
+    c = load_case(name)
+    if float(np.abs(c["mu1"]).max()) > 4.0 or float(np.abs(c["mu2"]).max()) > 4.0 or float(c["sigma"]) > 1.0:
+        pytest.skip("offsets beyond +-4 (or a prefilter wider than 11 taps): the exact kernels' case")
+    N, S, H, W = c["x"].shape
+    _, _, G, F = c["w"].shape
+    fl = _capi.FLAG_DENSE_SPLIT_F16
+    if int(c["use_interpolation"]): fl |= _capi.FLAG_USE_INTERPOLATION
+    if int(c["unit_testing"]): fl |= _capi.FLAG_UNIT_TESTING
+    if int(c["single_dim_kernel"]): fl |= _capi.FLAG_SINGLE_DIM_KERNEL
+    if int(c["forbid_positive_dim1"]): fl |= _capi.FLAG_FORBID_POSITIVE_DIM1
+    plan = _capi.Plan(N, S, F, G, H, W, max_kernel_size=case_kernel_size(c), number_units_ignore=int(c["ignore"]), flags=fl,
+                      sigma_hint=float(c["sigma"]))
+    assert plan.info["gather_dense_split"] == 0b11100
+    got = run_plan(plan, c["x"], c["dy"], c["w"], c["mu1"], c["mu2"], sigma=float(c["sigma"]))
+    for key in ("y", "dx", "dw", "dmu1", "dmu2", "dsigma"):
+        assert_parity(got[key], c[key], "golden/%s/split/%s" % (name, key), rel=1e-4, floor=3e-6)
 
 
 @pytest.mark.parametrize("scale", [1e-6, 1.0, 3e4])
