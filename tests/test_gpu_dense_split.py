@@ -144,6 +144,28 @@ def test_split_gather_is_scale_free(scale):
     assert np.array_equal(p2["dx"], base["dx"] * np.float32(2.0 ** -20))
 
 
+def test_split_gather_heavy_tailed_inputs():
+    """Activations after a ReLU (half of them exactly zero, a few three orders of magnitude above the rest) and gradients with the
+    same kind of outliers: the one scale per call is set by the outliers, the bulk sits 2^-10 below it and must keep its bits (the
+    second limb is then a binary16 subnormal for part of the data)."""
+    N, S, F, G, H, W = 2, 32, 32, 4, 24, 24
+    x, dy, w, mu1, mu2 = make_inputs(17, N, S, F, G, H, W, 9, 3.0)
+    rs = np.random.RandomState(99)
+    x = np.maximum(x - 0.5, 0.0).astype(np.float32)
+    x[rs.rand(*x.shape) < 1e-3] *= np.float32(1000.0)
+    dy = (dy * 1e-4).astype(np.float32)
+    dy[rs.rand(*dy.shape) < 1e-3] *= np.float32(1000.0)
+    plan = _plan(N, S, F, G, H, W)
+    got = run_plan(plan, x, dy, w, mu1, mu2)
+    want = _oracle(x, dy, w, mu1, mu2)
+    _check(got, want, "split/heavy-tailed")
+    # the bulk of the outputs (away from the outliers' footprints) must be as accurate as without them: compare with the run
+    # whose outliers are removed, on the outputs that do not change by more than rounding
+    calm = want["y"][np.abs(want["y"]) < np.percentile(np.abs(want["y"]), 90)]
+    err = (got["y"].astype(np.float64) - want["y"])[np.abs(want["y"]) < np.percentile(np.abs(want["y"]), 90)]
+    assert np.abs(err).max() <= 1e-4 * np.abs(calm).max() + 1e-6 * np.abs(want["y"]).max()
+
+
 def test_split_gather_zero_and_nonfinite_inputs():
     N, S, F, G, H, W = 2, 16, 16, 2, 16, 16
     x, dy, w, mu1, mu2 = make_inputs(3, N, S, F, G, H, W, 9, 3.0)
