@@ -54,7 +54,10 @@ def _run_DAUConv_forward_and_backward(N, W, H, S, F, dau_uints, max_kernel_size,
     # sigma is one scalar variable tiled to the parameter shape: its gradient is the sum (dau_conv.py:417-430)
     want = float(gt["dsigma"].astype(np.float64).sum())
     got = float(op.sigma.grad.item())
-    assert abs(got - want) <= 1e-4 * abs(want) + 1e-3 * float(np.abs(gt["dsigma"]).max()), (got, want)
+    # a sum of n = S*G*F signed per-unit gradients, each held to 1e-4 relative + 1e-6 of the max-norm: the errors of the terms add
+    # up like a random walk, so the sum gets the relative bar + 4 sqrt(n) floors (n = 4096: 2.6e-4 of max|dsigma|)
+    n_terms = gt["dsigma"].size
+    assert abs(got - want) <= 1e-4 * abs(want) + 4e-6 * np.sqrt(n_terms) * float(np.abs(gt["dsigma"]).max()), (got, want, n_terms)
     return op
 
 
