@@ -261,6 +261,55 @@ __device__ __forceinline__ int fast_div(int i, int d, float inv) {
     return q;
 }
 
+// the walk of one wave over its rows ya .. yb: lane column `col`, channels ch0 .. ch0 + NCH - 1 of the group's eight
+template <int K, int NCH>
+__device__ __forceinline__ void split_stage_walk(const float* rawl, const float* px, const float* py, float sx, int col, int ch0, int ya, int yb,
+                                                 int y0, int x0, int x1, int Ws, u32x4* xhi, u32x4* xlo) {
+    constexpr int kr = (K - 1) / 2;
+    const int x = x0 + col;
+    if (x >= x1) return;
+    float gx[K], gy[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) { gx[j] = px[j]; gy[j] = py[j]; }
+    float ring[K][NCH];
+    const int nin = yb - ya + 2 * kr;                        // input rows ya - kr .. yb + kr - 1
+    char* dhi = reinterpret_cast<char*>(xhi + (long)kDR * Ws + kDR + x) + ch0 * 2;
+    char* dlo = reinterpret_cast<char*>(xlo + (long)kDR * Ws + kDR + x) + ch0 * 2;
+    for (int s0 = 0; s0 < nin; s0 += K) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int s = s0 + j;
+            if (s < nin) {
+                const float* row = rawl + ((ya - y0 + s) * 8 + ch0) * kSP + 8 + col - kr;
+#pragma unroll
+                for (int ch = 0; ch < NCH; ++ch) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < K; ++i) acc = fmaf(row[ch * kSP + i], gx[i], acc);
+                    ring[j][ch] = acc;
+                }
+                if (s >= K - 1) {
+                    typedef _Float16 f16xn __attribute__((ext_vector_type(NCH)));
+                    f16xn oh, ol;
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ++ch) {
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < K; ++i) acc = fmaf(ring[(j + 1 + i) % K][ch], gy[i], acc);
+                        acc *= sx;
+                        const _Float16 hi = (_Float16)acc;
+                        oh[ch] = hi;
+                        ol[ch] = (_Float16)(acc - (float)hi);
+                    }
+                    const long o = (long)(ya + s - (K - 1)) * Ws * 16;
+                    *reinterpret_cast<f16xn*>(dhi + o) = oh;
+                    *reinterpret_cast<f16xn*>(dlo + o) = ol;
+                }
+            }
+        }
+    }
+}
+
 template <int K, bool BF>
 __global__ void __launch_bounds__(256) split_stage_kernel(const SplitStageArgs a) {
     extern __shared__ __attribute__((aligned(16))) float rawl[];   // [row][8 channels][kSP]
@@ -280,7 +329,7 @@ __global__ void __launch_bounds__(256) split_stage_kernel(const SplitStageArgs a
     // ---- raw window -> LDS: piece (r, ch, q) covers image row y0 - kr + r, columns x0 - 8 + 4q .. + 3 of channel grp*8 + ch
     {
         const int pieces = lh * 8 * PPR;
-        constexpr int UB = 4;
+        constexpr int UB = 13;          // loads in flight per thread: the whole window of a 14-row band (12.5 pieces per thread) in one batch
         for (int i0 = threadIdx.x; i0 < pieces; i0 += 256 * UB) {
             float4 v[UB];
             // branch-free loads (clamped address, masked value): a branch around a load makes hipcc wait for it at the join
@@ -338,55 +387,16 @@ __global__ void __launch_bounds__(256) split_stage_kernel(const SplitStageArgs a
         }
     }
     __syncthreads();
-    // ---- rows ya .. yb of this wave, lane = column
+    // ---- rows ya .. yb of this wave, lane = column; segments of at most 32 columns (maps up to 32 pixels wide) give the two half
+    // waves four channels each instead of leaving half of the lanes idle
     const int SR = (y1 - y0 + nw - 1) / nw;
     const int ya = y0 + wave * SR, yb = ya + SR < y1 ? ya + SR : y1;
-    const int x = x0 + lane;
-    if (ya >= yb || x >= x1) return;
-    float gx[K], gy[K];
-    {
-        const float* px = a.taps + (a.mirrored ? kTapGXR : kTapGX) * kTapPitch;
-        const float* py = a.taps + (a.mirrored ? kTapGYR : kTapGY) * kTapPitch;
-#pragma unroll
-        for (int j = 0; j < K; ++j) { gx[j] = px[j]; gy[j] = py[j]; }
-    }
+    if (ya >= yb) return;
+    const float* px = a.taps + (a.mirrored ? kTapGXR : kTapGX) * kTapPitch;
+    const float* py = a.taps + (a.mirrored ? kTapGYR : kTapGY) * kTapPitch;
     const float sx = a.sc->sx;
-    float ring[K][8];
-    const int nin = yb - ya + 2 * kr;                        // input rows ya - kr .. yb + kr - 1
-    u32x4* dhi = xhi + (long)kDR * a.Ws + kDR + x;
-    u32x4* dlo = xlo + (long)kDR * a.Ws + kDR + x;
-    for (int s0 = 0; s0 < nin; s0 += K) {
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const int s = s0 + j;
-            if (s < nin) {
-                const float* row = rawl + ((ya - y0 + s) * 8) * kSP + 8 + lane - kr;
-#pragma unroll
-                for (int ch = 0; ch < 8; ++ch) {
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < K; ++i) acc = fmaf(row[ch * kSP + i], gx[i], acc);
-                    ring[j][ch] = acc;
-                }
-                if (s >= K - 1) {
-                    f16x8 oh, ol;
-#pragma unroll
-                    for (int ch = 0; ch < 8; ++ch) {
-                        float acc = 0.0f;
-#pragma unroll
-                        for (int i = 0; i < K; ++i) acc = fmaf(ring[(j + 1 + i) % K][ch], gy[i], acc);
-                        acc *= sx;
-                        const _Float16 hi = (_Float16)acc;
-                        oh[ch] = hi;
-                        ol[ch] = (_Float16)(acc - (float)hi);
-                    }
-                    const long o = (long)(ya + s - (K - 1)) * a.Ws;
-                    dhi[o] = __builtin_bit_cast(u32x4, oh);
-                    dlo[o] = __builtin_bit_cast(u32x4, ol);
-                }
-            }
-        }
-    }
+    if (x1 - x0 <= 32) split_stage_walk<K, 4>(rawl, px, py, sx, lane & 31, (lane >> 5) * 4, ya, yb, y0, x0, x1, a.Ws, xhi, xlo);
+    else split_stage_walk<K, 8>(rawl, px, py, sx, lane, 0, ya, yb, y0, x0, x1, a.Ws, xhi, xlo);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -473,6 +483,14 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
     const long wlo = (long)a.CoutP * 2, wtap = 2 * wlo;      // f16x8 units
     const unsigned lane_base = (unsigned)(h * HALF + ((4 * pw + (nn >> 3)) * P + (nn & 7)) * 16);
 
+    // A wave whose four rows lie below the image (H = 28: the second half of the fourth row block) or whose 32 output channels lie
+    // beyond Cout (96 channels padded to 128) has nothing to compute: it keeps copying its share of the windows and meeting the
+    // barriers, and leaves the matrix pipe to its SIMD partner -- the kernel is bound by that pipe, so the workgroup finishes sooner.
+#ifdef DAU_SPLIT_NO_IDLE_WAVES           // (timing experiment: tools/build_variant.sh)
+    const bool live = true;
+#else
+    const bool live = rb * kDRows + 4 * pw < a.H && fb * kDFB + fw * 32 < a.Cout;
+#endif
     issue(0, 0);
     f16x8 ah[kDK], al[kDK], an[2], bn[2];                   // A fragments (hi, lo) of a row of taps; the next row's first two
     static_assert(kAhead == 2 && kDK >= 5 && kDK <= 9, "the A ring below is written for two taps ahead");
@@ -490,7 +508,7 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
         // are copied into place at the row's end.  Within a row: tap tx requests the A fragments of tap tx + 2 after its first
         // MFMA group, reads its lo fragments under the hi MFMAs and the next tap's hi fragments under the lo MFMAs.
 #pragma unroll 1
-        for (int ty = 0; ty < kDK; ++ty) {
+        for (int ty = 0; ty < (live ? kDK : 0); ++ty) {
             const unsigned brow = bbase + ty * P * 16;
             f16x8 xh[NSUB], xl[NSUB];
 #pragma unroll
