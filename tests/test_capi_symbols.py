@@ -92,6 +92,26 @@ def test_plan_validation_without_device():
     assert ut.info["drop_last_row"] == 1 and ut.info["drop_last_col"] == 0
 
 
+def test_which_dense_members_a_default_plan_holds():
+    """Plan creation needs no device: the radii of the two-limb f16 dense gather-sum a plan holds by default are those that pay
+    for its unit count on its tiling (split_pays, dau_conv_api.hip); the flags force all / none; the bf16-product dense flag and a
+    static bucket exclude them.  (The same table runs on the GPU in tests/test_gpu_dense_split.py.)"""
+    from dau_conv import _capi
+    for (S, F, G, H, W), want in (((256, 256, 4, 56, 56), 0b11100), ((256, 256, 6, 56, 56), 0b11100), ((256, 256, 2, 56, 56), 0b00100),
+                                  ((256, 256, 1, 56, 56), 0), ((96, 256, 4, 27, 27), 0b01100), ((512, 512, 4, 28, 28), 0b11100),
+                                  ((7, 5, 4, 16, 16), 0), ((64, 64, 2, 56, 56), 0), ((128, 128, 4, 16, 16), 0b11100)):
+        assert _capi.Plan(2, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5).info["gather_dense_split"] == want, (S, F, G, H, W)
+    I = _capi.FLAG_USE_INTERPOLATION
+    assert _capi.Plan(2, 7, 5, 1, 16, 16, flags=I | _capi.FLAG_DENSE_SPLIT_F16).info["gather_dense_split"] == 0b11100
+    assert _capi.Plan(2, 256, 256, 4, 56, 56, flags=I | _capi.FLAG_NO_DENSE_SPLIT).info["gather_dense_split"] == 0
+    assert _capi.Plan(2, 256, 256, 4, 56, 56, flags=I | _capi.FLAG_STATIC_BUCKET).info["gather_dense_split"] == 0
+    assert _capi.Plan(2, 256, 256, 4, 56, 56, flags=I | _capi.FLAG_IO_BF16 | _capi.FLAG_DENSE_BF16).info["gather_dense_split"] == 0
+    assert _capi.Plan(2, 256, 256, 4, 56, 56, max_kernel_size=65).info["gather_dense_split"] == 0b11100      # any kernel size: the members serve calls within +-4
+    assert _capi.Plan(2, 256, 256, 4, 56, 56, sigma_hint=1.2).info["gather_dense_split"] == 0                 # 13-tap prefilter: no staging instantiation
+    with pytest.raises(_capi.InvalidArgumentError):
+        _capi.Plan(2, 8, 8, 2, 8, 8, flags=I | _capi.FLAG_NO_DENSE_SPLIT | _capi.FLAG_DENSE_SPLIT_F16)
+
+
 def test_plan_cache_keys_on_the_prefilter_support_and_is_bounded():
     """A trainable sigma moves every optimizer step; a plan depends on it only through the prefilter support, so the cache
     must keep returning the same plan (with its kernel sets, hint and pending status) -- and it must not grow without bound."""
