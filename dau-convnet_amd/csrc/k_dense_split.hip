@@ -97,7 +97,9 @@ struct SplitGeom {
     int sub;                 // 8-pixel tiles per row
     // column blocks: nb_a blocks of nsub_a tiles from column 0, then nb_b blocks of nsub_b = nsub_a - 1 tiles (0 blocks when even)
     int nsub_a, nb_a, nsub_b, nb_b;
-    int nrb, Hs, Ws, nchunk, CoutP;
+    // row blocks: nrb8 blocks of eight rows from row 0, then -- where 1 .. 4 rows are left -- one block of four (nrb4 = 1)
+    int nrb8, nrb4;
+    int Hs, Ws, nchunk, CoutP;
     size_t hdr_bytes, xs_bytes, ws_bytes;
 };
 
@@ -107,8 +109,14 @@ SplitGeom split_geometry(const DenseConfig& c) {
     const int nblocks = (g.sub + kMaxSub - 1) / kMaxSub, base = g.sub / nblocks, rem = g.sub % nblocks;
     if (rem) { g.nsub_a = base + 1; g.nb_a = rem; g.nsub_b = base; g.nb_b = nblocks - rem; }
     else { g.nsub_a = base; g.nb_a = nblocks; g.nsub_b = 0; g.nb_b = 0; }
-    g.nrb = (c.H + kDRows - 1) / kDRows;
-    g.Hs = g.nrb * kDRows + kDSpan;
+    const int left = c.H % kDRows;
+    // the block of four rows is a launch of its own: it pays where the launches are many rounds of workgroups long (C3, 2048 workgroups:
+    // gather 6.6 -> 6.1 ms per pass), not where a pass is two rounds and the split makes it three (C1, 512 workgroups: 0.34 -> 0.41 ms)
+    const long wgs = (long)c.N * ((c.H + kDRows - 1) / kDRows) * nblocks * ((c.Cout + kDFB - 1) / kDFB);
+    const int rows4 = DAU_TUNE_INT("DAU_SPLIT_ROWS4", 1);    // tuning build: 0 never, 2 always (the variant tests)
+    g.nrb4 = (left >= 1 && left <= 4 && rows4 != 0 && (wgs >= 1024 || rows4 == 2)) ? 1 : 0;
+    g.nrb8 = c.H / kDRows + (left && !g.nrb4 ? 1 : 0);
+    g.Hs = g.nrb8 * kDRows + g.nrb4 * 4 + kDSpan;
     g.Ws = g.sub * 8 + kDSpan;
     g.nchunk = (c.Cin + 15) / 16;
     g.CoutP = (int)round_up(c.Cout, kDFB);
@@ -409,13 +417,20 @@ struct SplitArgs {
     float* out;               // [N][Cout][H][W], f32 or bf16
     int N, Cout, CoutP, H, W, Hs, Ws, nchunk, ncb, nrb, out_bf16;
     int col0;                 // first column of this launch's blocks (a row is covered by blocks of NSUB and of NSUB - 1 tiles)
+    int row0;                 // first row of this launch's row blocks (a map whose height leaves 1 .. 4 rows after its 8-row blocks
+                              // ends with one block of FOUR rows: RG = 1)
     Guard guard;
 };
 
-template <int NSUB>
+// RG: row groups (of four rows) per workgroup.  2: the eight waves are 4 (32 channels) x 2 (row groups), a wave owns the NSUB tiles of its
+// row group.  1: a block of four rows -- 4 (32 channels) x 2 (column halves), a wave owns (NSUB + 1) / 2 tiles; used for the last
+// 1 .. 4 rows of a map (28- and 27-pixel maps: 24 + 4 rows instead of 32).
+template <int NSUB, int RG = 2>
 __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
     constexpr int P = lds_pitch(NSUB);                       // LDS pitch (positions)
-    constexpr int WR = kDRows + kDSpan;                      // window rows
+    constexpr int kRowsWG = 4 * RG;                          // output rows per workgroup
+    constexpr int NT = RG == 2 ? NSUB : (NSUB + 1) / 2;      // tiles per wave
+    constexpr int WR = kRowsWG + kDSpan;                     // window rows
     constexpr int HALF = WR * P * 16;                        // bytes of one (limb, half) plane window
     constexpr int BUFU = 4 * WR * P;                         // 16-byte units of a window: [limb][half][row][P]
     constexpr int NPIECE = (BUFU + 63) / 64;                 // 1 KiB pieces (one global_load_lds wave instruction each)
@@ -425,7 +440,8 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
     if (!guard_pass(a.guard)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int fw = wave & 3, pw = wave >> 2;                 // channel part / row half of the workgroup tile
+    const int fw = wave & 3, pw = wave >> 2;                 // channel part / row group (RG = 2) or column half (RG = 1) of the workgroup tile
+    const int prow = RG == 2 ? 4 * pw : 0, ptile = RG == 2 ? 0 : pw * NT;   // first row / first tile of this wave inside the workgroup tile
     // Workgroups are dealt to the eight XCDs round robin (block b runs on XCD b % 8) and every XCD has its own L2: consecutive
     // LOGICAL ids -- the channel blocks of one window, then the next column block, the next row block (both share halo with it),
     // the same image -- are mapped to one XCD, so that a window is fetched from HBM once, not once per channel block
@@ -449,7 +465,8 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
     // Whole pitch rows are copied (c up to P - 1 reads past the window, into the row's tail or the next row: never used).
     const long xs_plane = (long)a.Hs * a.Ws;                 // 16-byte units per (n, chunk, limb, half)
     const int colb = a.col0 + cb * NSUB * 8;                 // first column of this block
-    const u32x4* xsrc = reinterpret_cast<const u32x4*>(a.xs) + ((long)n * a.nchunk * 4) * xs_plane + (long)(rb * kDRows) * a.Ws + colb;
+    const int rowb = a.row0 + rb * kRowsWG;                  // first row of this block
+    const u32x4* xsrc = reinterpret_cast<const u32x4*>(a.xs) + ((long)n * a.nchunk * 4) * xs_plane + (long)rowb * a.Ws + colb;
     int goff[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
@@ -470,18 +487,18 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
         }
     };
 
-    f32x16 sum[NSUB], acc[NSUB];                             // running sums; the current row of taps (chained from zero)
+    f32x16 sum[NT], acc[NT];                                 // running sums; the rows of taps being chained
     f32x16 zero;
 #pragma unroll
     for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
 #pragma unroll
-    for (int j = 0; j < NSUB; ++j) { sum[j] = zero; acc[j] = zero; }
+    for (int j = 0; j < NT; ++j) { sum[j] = zero; acc[j] = zero; }
     int rows_chained = 0;
 
     // A fragments: lane (nn, h) reads 16 bytes of channel fb*128 + fw*32 + nn; lo limb CoutP*2 units further
     const f16x8* wp = reinterpret_cast<const f16x8*>(a.wsd) + ((long)(fb * kDFB + fw * 32 + nn)) * 2 + h;
     const long wlo = (long)a.CoutP * 2, wtap = 2 * wlo;      // f16x8 units
-    const unsigned lane_base = (unsigned)(h * HALF + ((4 * pw + (nn >> 3)) * P + (nn & 7)) * 16);
+    const unsigned lane_base = (unsigned)(h * HALF + ((prow + (nn >> 3)) * P + ptile * 8 + (nn & 7)) * 16);
 
     // A wave whose four rows lie below the image (H = 28: the second half of the fourth row block) or whose 32 output channels lie
     // beyond Cout (96 channels padded to 128) has nothing to compute: it keeps copying its share of the windows and meeting the
@@ -489,7 +506,7 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
 #ifdef DAU_SPLIT_NO_IDLE_WAVES           // (timing experiment: tools/build_variant.sh)
     const bool live = true;
 #else
-    const bool live = rb * kDRows + 4 * pw < a.H && fb * kDFB + fw * 32 < a.Cout;
+    const bool live = rowb + prow < a.H && ptile < NSUB && colb + ptile * 8 < a.W && fb * kDFB + fw * 32 < a.Cout;
 #endif
     issue(0, 0);
     f16x8 ah[kDK], al[kDK], an[2], bn[2];                   // A fragments (hi, lo) of a row of taps; the next row's first two
@@ -510,49 +527,49 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
 #pragma unroll 1
         for (int ty = 0; ty < (live ? kDK : 0); ++ty) {
             const unsigned brow = bbase + ty * P * 16;
-            f16x8 xh[NSUB], xl[NSUB];
+            f16x8 xh[NT], xl[NT];
 #pragma unroll
-            for (int j = 0; j < NSUB; ++j) xh[j] = *reinterpret_cast<const f16x8*>(smem + brow + (8 * j) * 16);
+            for (int j = 0; j < NT; ++j) xh[j] = *reinterpret_cast<const f16x8*>(smem + brow + (8 * j) * 16);
 #pragma unroll
             for (int tx = 0; tx < kDK; ++tx) {
 #pragma unroll
-                for (int j = 0; j < NSUB; ++j) xl[j] = *reinterpret_cast<const f16x8*>(smem + brow + 2 * HALF + (tx + 8 * j) * 16);
+                for (int j = 0; j < NT; ++j) xl[j] = *reinterpret_cast<const f16x8*>(smem + brow + 2 * HALF + (tx + 8 * j) * 16);
 #pragma unroll
-                for (int j = 0; j < NSUB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tx], xh[j], (kFlushRows == 1 && tx % kFlushTaps == 0) ? zero : acc[j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tx], xh[j], (kFlushRows == 1 && tx % kFlushTaps == 0) ? zero : acc[j], 0, 0, 0);
                 if (tx + kAhead < kDK) { ah[tx + kAhead] = wp[(tx + kAhead) * wtap]; al[tx + kAhead] = wp[(tx + kAhead) * wtap + wlo]; }
                 if (tx == 2 || tx == 3) { an[tx - 2] = wp[(kDK + tx - 2) * wtap]; bn[tx - 2] = wp[(kDK + tx - 2) * wtap + wlo]; }
 #pragma unroll
-                for (int j = 0; j < NSUB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tx], xh[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tx], xh[j], acc[j], 0, 0, 0);
                 if (tx + 1 < kDK) {
 #pragma unroll
-                    for (int j = 0; j < NSUB; ++j) xh[j] = *reinterpret_cast<const f16x8*>(smem + brow + (tx + 1 + 8 * j) * 16);
+                    for (int j = 0; j < NT; ++j) xh[j] = *reinterpret_cast<const f16x8*>(smem + brow + (tx + 1 + 8 * j) * 16);
                 }
 #pragma unroll
-                for (int j = 0; j < NSUB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tx], xl[j], acc[j], 0, 0, 0);
+                for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tx], xl[j], acc[j], 0, 0, 0);
                 // the order hipcc must keep (left alone it sinks every LDS read to just before its MFMA and waits for it there)
-                if (tx == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NSUB, 0);
-                else __builtin_amdgcn_sched_group_barrier(0x100, NSUB, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, NSUB, 0);
+                if (tx == 0) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
                 if (tx == 2 || tx == 3) __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
                 else if (tx + kAhead < kDK) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, NSUB, 0);
-                if (tx + 1 < kDK) __builtin_amdgcn_sched_group_barrier(0x100, NSUB, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, NSUB, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+                if (tx + 1 < kDK) __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
                 if ((tx + 1) % kFlushTaps == 0 && tx + 1 < kDK) {
 #pragma unroll
-                    for (int j = 0; j < NSUB; ++j) sum[j] += acc[j];
+                    for (int j = 0; j < NT; ++j) sum[j] += acc[j];
                 }
             }
             wp += kDK * wtap;
             ah[0] = an[0]; al[0] = bn[0]; ah[1] = an[1]; al[1] = bn[1];
             if constexpr (kFlushRows == 1) {
 #pragma unroll
-                for (int j = 0; j < NSUB; ++j) sum[j] += acc[j];    // round-to-nearest adds of the row's partial sums
+                for (int j = 0; j < NT; ++j) sum[j] += acc[j];    // round-to-nearest adds of the row's partial sums
             } else {
                 if (++rows_chained == kFlushRows) {
                     rows_chained = 0;
 #pragma unroll
-                    for (int j = 0; j < NSUB; ++j) { sum[j] += acc[j]; acc[j] = zero; }
+                    for (int j = 0; j < NT; ++j) { sum[j] += acc[j]; acc[j] = zero; }
                 }
             }
         }
@@ -564,16 +581,16 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
 
     if constexpr (kFlushRows > 1) {
 #pragma unroll
-        for (int j = 0; j < NSUB; ++j) sum[j] += acc[j];     // the chain in progress
+        for (int j = 0; j < NT; ++j) sum[j] += acc[j];     // the chain in progress
     }
     // epilogue: C/D layout of the 32x32 tile: column (pixel) = lane & 31, row (channel) = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
     const float inv = a.sc->inv;
-    const int y = rb * kDRows + 4 * pw + (nn >> 3);
+    const int y = rowb + prow + (nn >> 3);
     const long plane = (long)a.H * a.W;
 #pragma unroll
-    for (int j = 0; j < NSUB; ++j) {
-        const int x = colb + 8 * j + (nn & 7);
-        if (y < a.H && x < a.W) {
+    for (int j = 0; j < NT; ++j) {
+        const int x = colb + 8 * (ptile + j) + (nn & 7);
+        if (y < a.H && x < a.W && ptile + j < NSUB) {          // (RG = 1, odd NSUB: the second column half's last tile does not exist)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int f = fb * kDFB + fw * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
@@ -588,22 +605,32 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-template <int NSUB>
-constexpr size_t split_lds_bytes() { return 2 * (size_t)((4 * (kDRows + kDSpan) * lds_pitch(NSUB) + 63) / 64) * 1024; }
+template <int NSUB, int RG>
+constexpr size_t split_lds_bytes() { return 2 * (size_t)((4 * (4 * RG + kDSpan) * lds_pitch(NSUB) + 63) / 64) * 1024; }
 
-template <int NSUB>
+template <int NSUB, int RG>
 void launch_split(hipStream_t st, const SplitArgs* a, int grid) {
-    auto kern = split_gather_kernel<NSUB>;
+    auto kern = split_gather_kernel<NSUB, RG>;
     if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return; }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), split_lds_bytes<NSUB>(), st, *a);
+    constexpr size_t lds = split_lds_bytes<NSUB, RG>();      // (a comma inside the launch macro's arguments would split them)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, *a);
 }
 
-void dispatch_split(int nsub, hipStream_t st, const SplitArgs* a, int grid) {
+void dispatch_split(int nsub, int rg, hipStream_t st, const SplitArgs* a, int grid) {
+    if (rg == 1) {
+        switch (nsub) {
+            case 1: launch_split<1, 1>(st, a, grid); break;
+            case 2: launch_split<2, 1>(st, a, grid); break;
+            case 3: launch_split<3, 1>(st, a, grid); break;
+            default: launch_split<4, 1>(st, a, grid); break;
+        }
+        return;
+    }
     switch (nsub) {
-        case 1: launch_split<1>(st, a, grid); break;
-        case 2: launch_split<2>(st, a, grid); break;
-        case 3: launch_split<3>(st, a, grid); break;
-        default: launch_split<4>(st, a, grid); break;
+        case 1: launch_split<1, 2>(st, a, grid); break;
+        case 2: launch_split<2, 2>(st, a, grid); break;
+        case 3: launch_split<3, 2>(st, a, grid); break;
+        default: launch_split<4, 2>(st, a, grid); break;
     }
 }
 
@@ -653,8 +680,11 @@ size_t split_gather_workspace_bytes(const DenseConfig& c) {
 
 void split_gather_init(const DenseConfig& c) {
     const SplitGeom g = split_geometry(c);
-    dispatch_split(g.nsub_a, nullptr, nullptr, 0);
-    if (g.nb_b) dispatch_split(g.nsub_b, nullptr, nullptr, 0);
+    for (int rg = 1; rg <= 2; ++rg) {
+        if (!(rg == 2 ? g.nrb8 : g.nrb4)) continue;
+        dispatch_split(g.nsub_a, rg, nullptr, nullptr, 0);
+        if (g.nb_b) dispatch_split(g.nsub_b, rg, nullptr, nullptr, 0);
+    }
     (void)hipFuncSetAttribute(stage_for(c.blur_k, c.bf16 != 0), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -693,12 +723,17 @@ void split_gather_run(hipStream_t st, const DenseConfig& c, float* out, void* wo
     a.wsd = reinterpret_cast<const _Float16*>(ws + g.hdr_bytes + g.xs_bytes);
     a.out = out;
     a.N = c.N; a.Cout = c.Cout; a.CoutP = g.CoutP; a.H = c.H; a.W = c.W; a.Hs = g.Hs; a.Ws = g.Ws; a.nchunk = g.nchunk;
-    a.nrb = g.nrb; a.out_bf16 = c.bf16; a.guard = guard;
-    a.ncb = g.nb_a; a.col0 = 0;
-    dispatch_split(g.nsub_a, st, &a, c.N * g.nrb * g.nb_a * (g.CoutP / kDFB));
-    if (g.nb_b) {
-        a.ncb = g.nb_b; a.col0 = g.nb_a * g.nsub_a * 8;
-        dispatch_split(g.nsub_b, st, &a, c.N * g.nrb * g.nb_b * (g.CoutP / kDFB));
+    a.out_bf16 = c.bf16; a.guard = guard;
+    for (int rg = 2; rg >= 1; --rg) {                        // the eight-row blocks, then the block of four rows where there is one
+        a.nrb = rg == 2 ? g.nrb8 : g.nrb4;
+        if (!a.nrb) continue;
+        a.row0 = rg == 2 ? 0 : g.nrb8 * kDRows;
+        a.ncb = g.nb_a; a.col0 = 0;
+        dispatch_split(g.nsub_a, rg, st, &a, c.N * a.nrb * g.nb_a * (g.CoutP / kDFB));
+        if (g.nb_b) {
+            a.ncb = g.nb_b; a.col0 = g.nb_a * g.nsub_a * 8;
+            dispatch_split(g.nsub_b, rg, st, &a, c.N * a.nrb * g.nb_b * (g.CoutP / kDFB));
+        }
     }
 }
 

@@ -40,7 +40,7 @@ def test_release_library_reads_no_tuning_knobs():
     shipped library must not even contain their names."""
     blob = open(LIB, "rb").read()
     for name in (b"DAU_DOT_", b"DAU_GATHER_", b"DAU_BLUR", b"DAU_DENSE_FT", b"DAU_DENSE_STAGE", b"DAU_DENSE_WGRAD",
-                 b"DAU_DENSE_SCATTER", b"DAU_DENSE_R3", b"DAU_WGRAD_", b"DAU_DYNAMIC_BUCKET", b"DAU_DIAG"):
+                 b"DAU_DENSE_SCATTER", b"DAU_DENSE_R3", b"DAU_DENSE_SPLIT", b"DAU_SPLIT_", b"DAU_WGRAD_", b"DAU_DYNAMIC_BUCKET", b"DAU_DIAG"):
         assert name not in blob, "release library contains the tuning knob %s*" % name.decode()
     assert b"DAU_WORKSPACE_BUDGET_GB" in blob
     tuning = LIB.replace("libdau_conv_hip.so", "libdau_conv_hip_tuning.so")

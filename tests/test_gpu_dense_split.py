@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import dau_oracle as orc
-from util import assert_parity, case_kernel_size, golden_cases, load_case, make_inputs, record_margins, run_plan
+from util import assert_parity, case_kernel_size, golden_cases, load_case, make_inputs, record_margins, run_plan, tuning_capi
 
 pytestmark = pytest.mark.gpu
 
@@ -56,6 +56,38 @@ def test_split_gather_against_oracle(shape, radius):
     assert plan.info["gather_dense_split"] == 0b11100
     got = run_plan(plan, x, dy, w, mu1, mu2)
     _check(got, _oracle(x, dy, w, mu1, mu2), "split/r%d/%dx%d" % (radius, H, W))
+
+
+@pytest.mark.parametrize("shape", [
+    dict(N=2, S=16, F=130, G=4, H=28, W=28),      # 24 + 4 rows; two column halves of two tiles
+    dict(N=3, S=20, F=40, G=3, H=27, W=45),       # 24 + 3 rows; blocks of three tiles: the second column half owns one
+    dict(N=2, S=7, F=5, G=2, H=3, W=6),           # the four-row block alone, one tile: the second column half is idle
+    dict(N=2, S=16, F=16, G=2, H=12, W=14),       # 8 + 4 rows, two tiles
+    dict(N=1, S=16, F=16, G=2, H=20, W=130),      # 16 + 4 rows, blocks of 4 / 3 tiles
+    dict(N=2, S=8, F=8, G=4, H=9, W=27),          # 8 + 1 rows
+])
+@pytest.mark.parametrize("radius", [2, 3, 4])
+def test_split_gather_block_of_four_rows(shape, radius, monkeypatch):
+    """The last 1 .. 4 rows of a map as a block of FOUR rows (split_gather_kernel<NSUB, RG = 1>: waves split the columns instead of
+    the rows).  Production takes that form only where a pass is many rounds of workgroups long (BASELINE config 3); the tuning build
+    forces it (DAU_SPLIT_ROWS4=2) on shapes the oracle finishes in no time."""
+    capi = tuning_capi()
+    monkeypatch.setenv("DAU_SPLIT_ROWS4", "2")
+    N, S, F, G, H, W = (shape[q] for q in ("N", "S", "F", "G", "H", "W"))
+    r = float(radius)
+    x, dy, w, mu1, mu2 = make_inputs(143 + radius, N, S, F, G, H, W, 9, r)
+    c = min(r, 3.99)
+    mu1.flat[0] = c; mu2.flat[0] = -c; mu1.flat[1] = -c; mu2.flat[1] = c
+    plan = capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=capi.FLAG_USE_INTERPOLATION | capi.FLAG_DENSE_SPLIT_F16)
+    got = run_plan(plan, x, dy, w, mu1, mu2)
+    want = _oracle(x, dy, w, mu1, mu2)
+    for key in ("y", "dx", "dw", "dmu1", "dmu2", "dsigma"):
+        assert_parity(got[key], want[key], "split/rows4/r%d/%dx%d/%s" % (radius, H, W, key))
+    monkeypatch.setenv("DAU_SPLIT_ROWS4", "0")      # the same call through eight-row blocks only: the same sums in the same order
+    plan8 = capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=capi.FLAG_USE_INTERPOLATION | capi.FLAG_DENSE_SPLIT_F16)
+    ref = run_plan(plan8, x, dy, w, mu1, mu2)
+    for key in ("y", "dx"):
+        assert np.array_equal(got[key], ref[key]), key
 
 
 @pytest.mark.parametrize("case", [
