@@ -45,6 +45,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
 
 #include "dau_tiled.hpp"
 
@@ -99,6 +100,7 @@ struct SplitGeom {
     int nsub_a, nb_a, nsub_b, nb_b;
     // row blocks: nrb8 blocks of eight rows from row 0, then -- where 1 .. 4 rows are left -- one block of four (nrb4 = 1)
     int nrb8, nrb4;
+    int tall;                // > 0: the eight-row blocks run as ONE column block of `tall` tiles of 8 rows x 4 columns (5 or 7)
     int Hs, Ws, nchunk, CoutP;
     size_t hdr_bytes, xs_bytes, ws_bytes;
 };
@@ -117,6 +119,16 @@ SplitGeom split_geometry(const DenseConfig& c) {
     g.nrb4 = (left >= 1 && left <= 4 && rows4 != 0 && (wgs >= 1024 || rows4 == 2)) ? 1 : 0;
     g.nrb8 = c.H / kDRows + (left && !g.nrb4 ? 1 : 0);
     g.Hs = g.nrb8 * kDRows + g.nrb4 * 4 + kDSpan;
+    {
+        // tall tiles where they compute at least 5 % fewer tile positions than the 4 x 8 ones (whose waves skip dead groups of four rows):
+        // 28 x 28 with a block of four rows: 24 x 28 + 4 x 32 against 28 x 32
+        const int t4 = (c.W + 3) / 4;
+        const long rows8 = (long)g.nrb8 * kDRows;
+        const long flat = (long)(g.nrb4 ? rows8 + 4 : (c.H + 3) / 4 * 4) * g.sub * 8;
+        const long tall = rows8 * t4 * 4 + (g.nrb4 ? 4L * g.sub * 8 : 0);
+        const int want = DAU_TUNE_INT("DAU_SPLIT_TALL", 1);  // tuning build: 0 never, 2 wherever the width allows (the variant tests)
+        g.tall = (want != 0 && g.nrb8 > 0 && (t4 == 5 || t4 == 7) && (tall * 20 <= flat * 19 || want == 2)) ? t4 : 0;
+    }
     g.Ws = g.sub * 8 + kDSpan;
     g.nchunk = (c.Cin + 15) / 16;
     g.CoutP = (int)round_up(c.Cout, kDFB);
@@ -130,6 +142,12 @@ SplitGeom split_geometry(const DenseConfig& c) {
 constexpr int lds_pitch(int nsub) {       // positions; = 8 (mod 16) and >= nsub*8 + span: the four rows of a B fragment hit different banks
     int p = nsub * 8 + kDSpan;
     while (p % 16 != 8) ++p;
+    return p;
+}
+// narrow tiles (8 rows x 4 columns): sixteen lanes read four columns of four rows -- conflict free at a pitch = 4 or 12 (mod 16)
+constexpr int lds_pitch_narrow(int ntiles) {
+    int p = ntiles * 4 + kDSpan;
+    while (p % 16 != 4 && p % 16 != 12) ++p;
     return p;
 }
 
@@ -425,11 +443,18 @@ struct SplitArgs {
 // RG: row groups (of four rows) per workgroup.  2: the eight waves are 4 (32 channels) x 2 (row groups), a wave owns the NSUB tiles of its
 // row group.  1: a block of four rows -- 4 (32 channels) x 2 (column halves), a wave owns (NSUB + 1) / 2 tiles; used for the last
 // 1 .. 4 rows of a map (28- and 27-pixel maps: 24 + 4 rows instead of 32).
-template <int NSUB, int RG = 2>
+// TT ("tall tiles", RG = 2 only): a tile is 8 rows x 4 columns instead of 4 rows x 8 columns and NSUB counts those; the workgroup is
+// 8 rows x NSUB*4 columns, its eight waves 4 (32 channels) x 2 (column halves of (NSUB + 1) / 2 and NSUB / 2 tiles -- the two waves of a
+// SIMD, so the SIMD's work is NSUB tiles).  For maps whose width is 1 .. 4 columns more than a multiple of eight (28 = 7 x 4: no padded
+// columns where 4 x 8 tiles pad to 32).
+template <int NSUB, int RG = 2, bool TT = false>
 __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
-    constexpr int P = lds_pitch(NSUB);                       // LDS pitch (positions)
+    static_assert(!TT || RG == 2, "tall tiles: blocks of eight rows");
+    constexpr int TW = TT ? 4 : 8;                           // columns of a tile
+    constexpr int P = TT ? lds_pitch_narrow(NSUB) : lds_pitch(NSUB);   // LDS pitch (positions)
     constexpr int kRowsWG = 4 * RG;                          // output rows per workgroup
-    constexpr int NT = RG == 2 ? NSUB : (NSUB + 1) / 2;      // tiles per wave
+    constexpr int NT0 = (RG == 2 && !TT) ? NSUB : (NSUB + 1) / 2;      // tiles per wave
+    constexpr int NT1 = TT ? NSUB / 2 : NT0;                 // ... of the second column half (tall tiles)
     constexpr int WR = kRowsWG + kDSpan;                     // window rows
     constexpr int HALF = WR * P * 16;                        // bytes of one (limb, half) plane window
     constexpr int BUFU = 4 * WR * P;                         // 16-byte units of a window: [limb][half][row][P]
@@ -440,8 +465,8 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
     if (!guard_pass(a.guard)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int fw = wave & 3, pw = wave >> 2;                 // channel part / row group (RG = 2) or column half (RG = 1) of the workgroup tile
-    const int prow = RG == 2 ? 4 * pw : 0, ptile = RG == 2 ? 0 : pw * NT;   // first row / first tile of this wave inside the workgroup tile
+    const int fw = wave & 3, pw = wave >> 2;                 // channel part / row group (RG = 2) or column half (RG = 1, TT) of the workgroup tile
+    const int prow = (RG == 2 && !TT) ? 4 * pw : 0, ptile = (RG == 2 && !TT) ? 0 : pw * NT0;   // first row / first tile of this wave inside the workgroup tile
     // Workgroups are dealt to the eight XCDs round robin (block b runs on XCD b % 8) and every XCD has its own L2: consecutive
     // LOGICAL ids -- the channel blocks of one window, then the next column block, the next row block (both share halo with it),
     // the same image -- are mapped to one XCD, so that a window is fetched from HBM once, not once per channel block
@@ -464,7 +489,7 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
     // window copy: LDS unit L = ((limb*2 + half) * WR + r) * P + c  <-  plane (limb, half), staged position (rb*8 + r, cb*NSUB*8 + c).
     // Whole pitch rows are copied (c up to P - 1 reads past the window, into the row's tail or the next row: never used).
     const long xs_plane = (long)a.Hs * a.Ws;                 // 16-byte units per (n, chunk, limb, half)
-    const int colb = a.col0 + cb * NSUB * 8;                 // first column of this block
+    const int colb = a.col0 + cb * NSUB * TW;                // first column of this block
     const int rowb = a.row0 + rb * kRowsWG;                  // first row of this block
     const u32x4* xsrc = reinterpret_cast<const u32x4*>(a.xs) + ((long)n * a.nchunk * 4) * xs_plane + (long)rowb * a.Ws + colb;
     int goff[PPW];
@@ -487,6 +512,13 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
         }
     };
 
+    const int prr = TT ? nn >> 2 : nn >> 3, pcc = TT ? nn & 3 : nn & 7;   // this lane's position inside a tile
+    // (kernel arguments the epilogue uses, read once: inside the lambda hipcc reloads them from the argument segment at every store)
+    float* const out_ptr = a.out;
+    const bool out_bf16 = a.out_bf16 != 0;
+    const int out_c = a.Cout, out_h = a.H, out_w = a.W;
+    auto body = [&](auto ntc) __attribute__((always_inline)) {
+    constexpr int NT = decltype(ntc)::value;                 // tiles of this wave
     f32x16 sum[NT], acc[NT];                                 // running sums; the rows of taps being chained
     f32x16 zero;
 #pragma unroll
@@ -498,7 +530,7 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
     // A fragments: lane (nn, h) reads 16 bytes of channel fb*128 + fw*32 + nn; lo limb CoutP*2 units further
     const f16x8* wp = reinterpret_cast<const f16x8*>(a.wsd) + ((long)(fb * kDFB + fw * 32 + nn)) * 2 + h;
     const long wlo = (long)a.CoutP * 2, wtap = 2 * wlo;      // f16x8 units
-    const unsigned lane_base = (unsigned)(h * HALF + ((prow + (nn >> 3)) * P + ptile * 8 + (nn & 7)) * 16);
+    const unsigned lane_base = (unsigned)(h * HALF + ((prow + prr) * P + ptile * TW + pcc) * 16);
 
     // A wave whose four rows lie below the image (H = 28: the second half of the fourth row block) or whose 32 output channels lie
     // beyond Cout (96 channels padded to 128) has nothing to compute: it keeps copying its share of the windows and meeting the
@@ -506,7 +538,7 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
 #ifdef DAU_SPLIT_NO_IDLE_WAVES           // (timing experiment: tools/build_variant.sh)
     const bool live = true;
 #else
-    const bool live = rowb + prow < a.H && ptile < NSUB && colb + ptile * 8 < a.W && fb * kDFB + fw * 32 < a.Cout;
+    const bool live = rowb + prow < a.H && ptile < NSUB && colb + ptile * TW < a.W && fb * kDFB + fw * 32 < a.Cout;
 #endif
     issue(0, 0);
     f16x8 ah[kDK], al[kDK], an[2], bn[2];                   // A fragments (hi, lo) of a row of taps; the next row's first two
@@ -529,11 +561,11 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
             const unsigned brow = bbase + ty * P * 16;
             f16x8 xh[NT], xl[NT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) xh[j] = *reinterpret_cast<const f16x8*>(smem + brow + (8 * j) * 16);
+            for (int j = 0; j < NT; ++j) xh[j] = *reinterpret_cast<const f16x8*>(smem + brow + (TW * j) * 16);
 #pragma unroll
             for (int tx = 0; tx < kDK; ++tx) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) xl[j] = *reinterpret_cast<const f16x8*>(smem + brow + 2 * HALF + (tx + 8 * j) * 16);
+                for (int j = 0; j < NT; ++j) xl[j] = *reinterpret_cast<const f16x8*>(smem + brow + 2 * HALF + (tx + TW * j) * 16);
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tx], xh[j], (kFlushRows == 1 && tx % kFlushTaps == 0) ? zero : acc[j], 0, 0, 0);
                 if (tx + kAhead < kDK) { ah[tx + kAhead] = wp[(tx + kAhead) * wtap]; al[tx + kAhead] = wp[(tx + kAhead) * wtap + wlo]; }
@@ -542,7 +574,7 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
                 for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tx], xh[j], acc[j], 0, 0, 0);
                 if (tx + 1 < kDK) {
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) xh[j] = *reinterpret_cast<const f16x8*>(smem + brow + (tx + 1 + 8 * j) * 16);
+                    for (int j = 0; j < NT; ++j) xh[j] = *reinterpret_cast<const f16x8*>(smem + brow + (tx + 1 + TW * j) * 16);
                 }
 #pragma unroll
                 for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tx], xl[j], acc[j], 0, 0, 0);
@@ -585,18 +617,26 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
     }
     // epilogue: C/D layout of the 32x32 tile: column (pixel) = lane & 31, row (channel) = (i & 3) + 8 (i >> 2) + 4 (lane >> 5)
     const float inv = a.sc->inv;
-    const int y = rowb + prow + (nn >> 3);
-    const long plane = (long)a.H * a.W;
+    const int y = rowb + prow + prr;
+    const long plane = (long)out_h * out_w;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        const int x = colb + 8 * (ptile + j) + (nn & 7);
-        if (y < a.H && x < a.W && ptile + j < NSUB) {          // (RG = 1, odd NSUB: the second column half's last tile does not exist)
+        const int x = colb + TW * (ptile + j) + pcc;
+        if (y < out_h && x < out_w && ptile + j < NSUB) {      // (RG = 1, odd NSUB: the second column half's last tile does not exist)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int f = fb * kDFB + fw * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (f < a.Cout) store_act(a.out, ((long)n * a.Cout + f) * plane + (long)y * a.W + x, sum[j][i] * inv, a.out_bf16 != 0, false);
+                if (f < out_c) store_act(out_ptr, ((long)n * out_c + f) * plane + (long)y * out_w + x, sum[j][i] * inv, out_bf16, false);
             }
         }
+    }
+    };
+    // (both branches meet the same barriers: one per chunk)
+    if constexpr (TT) {
+        if (pw == 0) body(std::integral_constant<int, NT0>{});
+        else body(std::integral_constant<int, NT1>{});
+    } else {
+        body(std::integral_constant<int, NT0>{});
     }
 }
 
@@ -605,18 +645,23 @@ __global__ void __launch_bounds__(512) split_gather_kernel(const SplitArgs a) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-template <int NSUB, int RG>
-constexpr size_t split_lds_bytes() { return 2 * (size_t)((4 * (4 * RG + kDSpan) * lds_pitch(NSUB) + 63) / 64) * 1024; }
+template <int NSUB, int RG, bool TT>
+constexpr size_t split_lds_bytes() { return 2 * (size_t)((4 * (4 * RG + kDSpan) * (TT ? lds_pitch_narrow(NSUB) : lds_pitch(NSUB)) + 63) / 64) * 1024; }
 
-template <int NSUB, int RG>
+template <int NSUB, int RG, bool TT = false>
 void launch_split(hipStream_t st, const SplitArgs* a, int grid) {
-    auto kern = split_gather_kernel<NSUB, RG>;
+    auto kern = split_gather_kernel<NSUB, RG, TT>;
     if (!a) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return; }
-    constexpr size_t lds = split_lds_bytes<NSUB, RG>();      // (a comma inside the launch macro's arguments would split them)
+    constexpr size_t lds = split_lds_bytes<NSUB, RG, TT>();      // (a comma inside the launch macro's arguments would split them)
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, *a);
 }
 
-void dispatch_split(int nsub, int rg, hipStream_t st, const SplitArgs* a, int grid) {
+void dispatch_split(int nsub, int rg, hipStream_t st, const SplitArgs* a, int grid, bool tall = false) {
+    if (tall) {                                              // nsub = tiles of four columns: 5 or 7 (split_geometry)
+        if (nsub == 5) launch_split<5, 2, true>(st, a, grid);
+        else launch_split<7, 2, true>(st, a, grid);
+        return;
+    }
     if (rg == 1) {
         switch (nsub) {
             case 1: launch_split<1, 1>(st, a, grid); break;
@@ -682,6 +727,7 @@ void split_gather_init(const DenseConfig& c) {
     const SplitGeom g = split_geometry(c);
     for (int rg = 1; rg <= 2; ++rg) {
         if (!(rg == 2 ? g.nrb8 : g.nrb4)) continue;
+        if (rg == 2 && g.tall) { dispatch_split(g.tall, 2, nullptr, nullptr, 0, true); continue; }
         dispatch_split(g.nsub_a, rg, nullptr, nullptr, 0);
         if (g.nb_b) dispatch_split(g.nsub_b, rg, nullptr, nullptr, 0);
     }
@@ -728,6 +774,11 @@ void split_gather_run(hipStream_t st, const DenseConfig& c, float* out, void* wo
         a.nrb = rg == 2 ? g.nrb8 : g.nrb4;
         if (!a.nrb) continue;
         a.row0 = rg == 2 ? 0 : g.nrb8 * kDRows;
+        if (rg == 2 && g.tall) {                             // one column block of tall tiles
+            a.ncb = 1; a.col0 = 0;
+            dispatch_split(g.tall, 2, st, &a, c.N * a.nrb * (g.CoutP / kDFB), true);
+            continue;
+        }
         a.ncb = g.nb_a; a.col0 = 0;
         dispatch_split(g.nsub_a, rg, st, &a, c.N * a.nrb * g.nb_a * (g.CoutP / kDFB));
         if (g.nb_b) {

@@ -90,6 +90,39 @@ def test_split_gather_block_of_four_rows(shape, radius, monkeypatch):
         assert np.array_equal(got[key], ref[key]), key
 
 
+@pytest.mark.parametrize("shape", [
+    dict(N=2, S=16, F=16, G=4, H=28, W=28),       # config 3's map: 3 blocks of 8 rows x 7 tall tiles + the block of four rows
+    dict(N=2, S=7, F=5, G=2, H=13, W=27),         # 7 tiles, the last one three columns wide; 8 + 5 rows
+    dict(N=1, S=16, F=130, G=2, H=8, W=25),       # 7 tiles, one live column in the last; two channel blocks
+    dict(N=2, S=8, F=8, G=4, H=16, W=20),         # 5 tiles (3 + 2)
+    dict(N=2, S=24, F=8, G=3, H=11, W=17),        # 5 tiles, one live column in the last; 8 + 3 rows
+])
+@pytest.mark.parametrize("rows4", ["0", "2"])
+@pytest.mark.parametrize("radius", [2, 3, 4])
+def test_split_gather_tall_tiles(shape, radius, rows4, monkeypatch):
+    """Tiles of 8 rows x 4 columns (split_gather_kernel<NSUB, 2, TT = true>) for widths that are 1 .. 4 columns more than a
+    multiple of eight: a 28-pixel row is seven tiles instead of four padded ones.  Production takes them where they compute at
+    least 5 % fewer tile positions (BASELINE config 3); the tuning build forces them (DAU_SPLIT_TALL=2), with and without the
+    block of four rows beside them."""
+    capi = tuning_capi()
+    monkeypatch.setenv("DAU_SPLIT_TALL", "2")
+    monkeypatch.setenv("DAU_SPLIT_ROWS4", rows4)
+    N, S, F, G, H, W = (shape[q] for q in ("N", "S", "F", "G", "H", "W"))
+    r = float(radius)
+    x, dy, w, mu1, mu2 = make_inputs(151 + radius, N, S, F, G, H, W, 9, r)
+    c = min(r, 3.99)
+    mu1.flat[0] = c; mu2.flat[0] = -c; mu1.flat[1] = -c; mu2.flat[1] = c
+    flags = capi.FLAG_USE_INTERPOLATION | capi.FLAG_DENSE_SPLIT_F16
+    got = run_plan(capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=flags), x, dy, w, mu1, mu2)
+    want = _oracle(x, dy, w, mu1, mu2)
+    for key in ("y", "dx", "dw", "dmu1", "dmu2", "dsigma"):
+        assert_parity(got[key], want[key], "split/tall/r%d/%dx%d/%s" % (radius, H, W, key))
+    monkeypatch.setenv("DAU_SPLIT_TALL", "0")       # the same call through 4 x 8 tiles: the same sums in the same order
+    ref = run_plan(capi.Plan(N, S, F, G, H, W, max_kernel_size=9, sigma_hint=0.5, flags=flags), x, dy, w, mu1, mu2)
+    for key in ("y", "dx"):
+        assert np.array_equal(got[key], ref[key]), key
+
+
 @pytest.mark.parametrize("case", [
     # (S, F, G, H, W) -> the radii a default plan holds: those that pay for the unit count on this tiling (split_pays, dau_conv_api.hip)
     ((256, 256, 4, 56, 56), 0b11100), ((256, 256, 6, 56, 56), 0b11100), ((256, 256, 2, 56, 56), 0b00100),
