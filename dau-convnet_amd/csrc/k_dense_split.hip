@@ -287,16 +287,43 @@ __device__ __forceinline__ int fast_div(int i, int d, float inv) {
     return q;
 }
 
-// the walk of one wave over its rows ya .. yb: lane column `col`, channels ch0 .. ch0 + NCH - 1 of the group's eight
+// Horizontal pass, IN PLACE: the waves share the rows of the band's window (row r = wave, wave + nw, ...); a lane filters its column
+// of NCH channels and writes the results over the raw values.  In place is safe because a row segment belongs to ONE wave: every read
+// of a channel's row precedes the write of that channel in the wave's instruction stream (the written value depends on all of them)
+// and a wave's LDS operations execute in order.  (Before: every wave filtered the K - 1 halo rows of its own rows again -- ten rows
+// for four at the north-star shape.)
 template <int K, int NCH>
-__device__ __forceinline__ void split_stage_walk(const float* rawl, const float* px, const float* py, float sx, int col, int ch0, int ya, int yb,
+__device__ __forceinline__ void split_stage_rows(float* rawl, const float* px, int col, int ch0, int wave, int nw, int lh, int ncols) {
+    constexpr int kr = (K - 1) / 2;
+    if (col >= ncols) return;
+    float gx[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) gx[j] = px[j];
+    for (int r = wave; r < lh; r += nw) {
+        float* row = rawl + (r * 8 + ch0) * kSP + 8 + col;
+        float acc[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            acc[ch] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < K; ++i) acc[ch] = fmaf(row[ch * kSP + i - kr], gx[i], acc[ch]);
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) row[ch * kSP] = acc[ch];
+    }
+}
+
+// the walk of one wave over its rows ya .. yb: lane column `col`, channels ch0 .. ch0 + NCH - 1 of the group's eight; vertical pass over
+// a register ring of K horizontally filtered rows (rawl after split_stage_rows), scale, split, store
+template <int K, int NCH>
+__device__ __forceinline__ void split_stage_walk(const float* rawl, const float* py, float sx, int col, int ch0, int ya, int yb,
                                                  int y0, int x0, int x1, int Ws, u32x4* xhi, u32x4* xlo) {
     constexpr int kr = (K - 1) / 2;
     const int x = x0 + col;
     if (x >= x1) return;
-    float gx[K], gy[K];
+    float gy[K];
 #pragma unroll
-    for (int j = 0; j < K; ++j) { gx[j] = px[j]; gy[j] = py[j]; }
+    for (int j = 0; j < K; ++j) gy[j] = py[j];
     float ring[K][NCH];
     const int nin = yb - ya + 2 * kr;                        // input rows ya - kr .. yb + kr - 1
     char* dhi = reinterpret_cast<char*>(xhi + (long)kDR * Ws + kDR + x) + ch0 * 2;
@@ -306,14 +333,9 @@ __device__ __forceinline__ void split_stage_walk(const float* rawl, const float*
         for (int j = 0; j < K; ++j) {
             const int s = s0 + j;
             if (s < nin) {
-                const float* row = rawl + ((ya - y0 + s) * 8 + ch0) * kSP + 8 + col - kr;
+                const float* row = rawl + ((ya - y0 + s) * 8 + ch0) * kSP + 8 + col;
 #pragma unroll
-                for (int ch = 0; ch < NCH; ++ch) {
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < K; ++i) acc = fmaf(row[ch * kSP + i], gx[i], acc);
-                    ring[j][ch] = acc;
-                }
+                for (int ch = 0; ch < NCH; ++ch) ring[j][ch] = row[ch * kSP];
                 if (s >= K - 1) {
                     typedef _Float16 f16xn __attribute__((ext_vector_type(NCH)));
                     f16xn oh, ol;
@@ -336,8 +358,12 @@ __device__ __forceinline__ void split_stage_walk(const float* rawl, const float*
     }
 }
 
+#ifndef DAU_SPLIT_STAGE_THREADS
+#define DAU_SPLIT_STAGE_THREADS 512        // eight waves share a band (same box: 375 us per pass at the north-star shape with 256 threads, 362 with 512)
+#endif
+constexpr int kStageThreads = DAU_SPLIT_STAGE_THREADS;
 template <int K, bool BF>
-__global__ void __launch_bounds__(256) split_stage_kernel(const SplitStageArgs a) {
+__global__ void __launch_bounds__(kStageThreads) split_stage_kernel(const SplitStageArgs a) {
     extern __shared__ __attribute__((aligned(16))) float rawl[];   // [row][8 channels][kSP]
     if (!guard_pass(a.guard)) return;
     constexpr int kr = (K - 1) / 2;
@@ -355,13 +381,13 @@ __global__ void __launch_bounds__(256) split_stage_kernel(const SplitStageArgs a
     // ---- raw window -> LDS: piece (r, ch, q) covers image row y0 - kr + r, columns x0 - 8 + 4q .. + 3 of channel grp*8 + ch
     {
         const int pieces = lh * 8 * PPR;
-        constexpr int UB = 13;          // loads in flight per thread: the whole window of a 14-row band (12.5 pieces per thread) in one batch
-        for (int i0 = threadIdx.x; i0 < pieces; i0 += 256 * UB) {
+        constexpr int UB = (13 * 256 + kStageThreads - 1) / kStageThreads;   // loads in flight per thread: the whole window of a 14-row band (12.5 pieces per thread of 256) in one batch
+        for (int i0 = threadIdx.x; i0 < pieces; i0 += kStageThreads * UB) {
             float4 v[UB];
             // branch-free loads (clamped address, masked value): a branch around a load makes hipcc wait for it at the join
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
-                const int i = i0 + u * 256, rc = i / PPR, q = i - rc * PPR, r = rc >> 3, ch = rc & 7;
+                const int i = i0 + u * kStageThreads, rc = i / PPR, q = i - rc * PPR, r = rc >> 3, ch = rc & 7;
                 const int c = grp * 8 + ch, y = y0 - kr + r, xs = x0 - 8 + 4 * q;
                 const bool row_in = c < a.C && y >= 0 && y < a.H && i < pieces;
                 const long base = ((long)n * a.C + (c < a.C ? c : 0)) * plane;
@@ -389,7 +415,7 @@ __global__ void __launch_bounds__(256) split_stage_kernel(const SplitStageArgs a
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
-                const int i = i0 + u * 256;
+                const int i = i0 + u * kStageThreads;
                 if (i < pieces) *reinterpret_cast<float4*>(rawl + (long)i * 4) = v[u];      // piece i sits at [r][ch][4q]: i * 4 floats
             }
         }
@@ -413,16 +439,21 @@ __global__ void __launch_bounds__(256) split_stage_kernel(const SplitStageArgs a
         }
     }
     __syncthreads();
-    // ---- rows ya .. yb of this wave, lane = column; segments of at most 32 columns (maps up to 32 pixels wide) give the two half
-    // waves four channels each instead of leaving half of the lanes idle
+    // lane = column; segments of at most 32 columns (maps up to 32 pixels wide) give the two half waves four channels each instead of
+    // leaving half of the lanes idle
+    const float* px = a.taps + (a.mirrored ? kTapGXR : kTapGX) * kTapPitch;
+    const float* py = a.taps + (a.mirrored ? kTapGYR : kTapGY) * kTapPitch;
+    // ---- horizontal pass over every row of the window, in place (the waves share the rows)
+    if (x1 - x0 <= 32) split_stage_rows<K, 4>(rawl, px, lane & 31, (lane >> 5) * 4, wave, nw, lh, x1 - x0);
+    else split_stage_rows<K, 8>(rawl, px, lane, 0, wave, nw, lh, x1 - x0);
+    __syncthreads();
+    // ---- vertical pass, scale, split, store: rows ya .. yb of this wave
     const int SR = (y1 - y0 + nw - 1) / nw;
     const int ya = y0 + wave * SR, yb = ya + SR < y1 ? ya + SR : y1;
     if (ya >= yb) return;
-    const float* px = a.taps + (a.mirrored ? kTapGXR : kTapGX) * kTapPitch;
-    const float* py = a.taps + (a.mirrored ? kTapGYR : kTapGY) * kTapPitch;
     const float sx = a.sc->sx;
-    if (x1 - x0 <= 32) split_stage_walk<K, 4>(rawl, px, py, sx, lane & 31, (lane >> 5) * 4, ya, yb, y0, x0, x1, a.Ws, xhi, xlo);
-    else split_stage_walk<K, 8>(rawl, px, py, sx, lane, 0, ya, yb, y0, x0, x1, a.Ws, xhi, xlo);
+    if (x1 - x0 <= 32) split_stage_walk<K, 4>(rawl, py, sx, lane & 31, (lane >> 5) * 4, ya, yb, y0, x0, x1, a.Ws, xhi, xlo);
+    else split_stage_walk<K, 8>(rawl, py, sx, lane, 0, ya, yb, y0, x0, x1, a.Ws, xhi, xlo);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -757,7 +788,7 @@ void split_gather_prepare(hipStream_t st, const DenseConfig& c, const float* in,
     s.nsegs = (c.W + 63) / 64;
     s.vec = c.W % 4 == 0 && reinterpret_cast<uintptr_t>(in) % 16 == 0;
     void* args[] = {&s};
-    (void)hipLaunchKernel(stage_for(c.blur_k, c.bf16 != 0), dim3(c.N * 2 * g.nchunk * s.nbands * s.nsegs), dim3(256), args, lds, st);
+    (void)hipLaunchKernel(stage_for(c.blur_k, c.bf16 != 0), dim3(c.N * 2 * g.nchunk * s.nbands * s.nsegs), dim3(kStageThreads), args, lds, st);
 }
 
 void split_gather_run(hipStream_t st, const DenseConfig& c, float* out, void* workspace, const Guard& guard) {
